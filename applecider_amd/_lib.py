@@ -1,0 +1,134 @@
+"""ctypes binding of libapplecider_hip.so (C ABI declared in include/applecider_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a
+kernel is asked to run on a non-GPU tensor, this module raises.  Only the
+in-tree build (``applecider_amd/csrc/libapplecider_hip.so``) is ever loaded.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
+
+AC_GEMM_NT, AC_GEMM_NN, AC_GEMM_TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+MATH_F32, MATH_BF16 = 0, 1
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU,
+             "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH}
+
+
+class RowMap(C.Structure):
+    _fields_ = [("r1", C.c_int32), ("r2", C.c_int32), ("s1", C.c_int64), ("s2", C.c_int64),
+                ("s3", C.c_int64)]
+
+
+class Mat(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("rows", RowMap), ("goff", C.c_void_p)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("math", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("act", C.c_int32), ("dact", C.c_int32), ("accumulate", C.c_int32),
+        ("split_k", C.c_int32), ("force_simple", C.c_int32),
+        ("alpha", C.c_float), ("_pad0", C.c_int32),
+        ("a", Mat), ("b", Mat), ("c", Mat),
+        ("bias", C.c_void_p), ("pre_out", C.c_void_p), ("ld_pre", C.c_int64),
+        ("aux", C.c_void_p), ("ld_aux", C.c_int64),
+        ("colscale", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),
+    ]
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("decoupled", C.c_int32)]
+
+
+_P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> argtypes (return type is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "ac_abi_version": [],
+    "ac_strerror": [_I32],
+    "ac_gemm": [C.POINTER(GemmDesc), _P],
+    "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P],
+    "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _P],
+    "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ac_act_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "ac_act_fwd": [_P, _P, _I64, _I32, _P],
+    "ac_copy2d": [_P, _I64, _P, _I64, _I64, _I32, _P],
+    "ac_gather_cols": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
+    "ac_gate_fwd": [_P, _P, _P, _P, _I64, _P],
+    "ac_gate_bwd": [_P, _P, _P, _P, _P, _I64, _P],
+    "ac_dropout": [_P, _P, _I64, _F, _U64, _U64, _P],
+    "ac_layerscale_bwd": [_P, _P, _P, _P, _P, _I64, _I32, _P],
+    "ac_add": [_P, _P, _P, _I64, _F, _P],
+    "ac_scale_by_dev": [_P, _I64, _P, _P],
+    "ac_stem_patchify": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_dwconv7x7_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_dwconv7x7_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_avgpool_fwd": [_P, _P, _I32, _I32, _I32, _P],
+    "ac_avgpool_bwd": [_P, _P, _I32, _I32, _I32, _P],
+    "ac_maxpool4_fwd": [_P, _P, _I64, _P, _I32, _I32, _I32, _P],
+    "ac_maxpool4_bwd": [_P, _I64, _P, _P, _I32, _I32, _I32, _P],
+    "ac_globalmax_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_globalmax_bwd": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_pad_rows": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "ac_toeplitz_expand": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_toeplitz_fold": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_embed_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_moe_top2_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_moe_top2_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ac_l2norm_fwd": [_P, _P, _P, _I64, _I32, _P],
+    "ac_l2norm_bwd": [_P, _P, _P, _P, _I64, _I32, _P],
+    "ac_softmax_fwd": [_P, _P, _I64, _I32, _P],
+    "ac_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _P],
+    "ac_adam_flat": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _I32, _P, _P],
+    "ac_sgd_flat": [_P, _P, _P, _I64, _F, _F, _F, _I32, _P],
+    "ac_sumsq": [_P, _I64, _P, _P],
+    "ac_clip_coef": [_P, _F, _P, _P],
+}
+_RESTYPES = {"ac_strerror": C.c_char_p}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the in-tree shared library (once).  Raises HipLibraryMissing loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  applecider_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.ac_abi_version() != 1:
+        raise HipLibraryMissing(f"ABI version mismatch: {lib.ac_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().ac_strerror(code).decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: code {rc} ({strerror(rc)})")

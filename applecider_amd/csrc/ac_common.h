@@ -1,0 +1,76 @@
+// Internal helpers shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/applecider_hip.h"
+
+#define AC_WAVE 64
+
+#define AC_CHECK_LAUNCH()                              \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return -(int)e__ - 2000; \
+    } while (0)
+
+static inline bool ac_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+__device__ __forceinline__ float ac_gelu(float x) {
+    // exact erf GELU (torch default approximate='none')
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float ac_gelu_grad(float x) {
+    const float kInvSqrt2Pi = 0.39894228040143267794f;
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float ac_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float ac_act(float v, int kind) {
+    switch (kind) {
+        case AC_ACT_GELU: return ac_gelu(v);
+        case AC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case AC_ACT_SIGMOID: return ac_sigmoid(v);
+        case AC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative from aux: GELU/RELU take the pre-activation, SIGMOID/TANH the output
+__device__ __forceinline__ float ac_dact(float aux, int kind) {
+    switch (kind) {
+        case AC_ACT_GELU: return ac_gelu_grad(aux);
+        case AC_ACT_RELU: return aux > 0.f ? 1.f : 0.f;
+        case AC_ACT_SIGMOID: return aux * (1.f - aux);
+        case AC_ACT_TANH: return 1.f - aux * aux;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float ac_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float ac_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based keep/drop decision shared by forward and backward (dropout):
+// a 64-bit mix (splitmix64 finaliser) of (seed, index) -> uniform in [0,1).
+__device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ int64_t ac_rowaddr(const ac_rowmap &m, int r) {
+    if (m.r1 == 0) return (int64_t)r * m.s3;
+    int q1 = r / m.r1;
+    int rem = r - q1 * m.r1;
+    int q2 = rem / m.r2;
+    int q3 = rem - q2 * m.r2;
+    return (int64_t)q1 * m.s1 + (int64_t)q2 * m.s2 + (int64_t)q3 * m.s3;
+}

@@ -1,0 +1,365 @@
+// Row-wise kernels: LayerNorm (+GELU) fwd/bwd, column sums, L2 normalise, softmax, losses.
+// All are HBM-bound streaming kernels: one wave per row, lanes stride the channel
+// dimension with 16-byte accesses when C % 4 == 0; re-reads of a row hit L1/L2.
+#include "ac_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ROWS_BLOCK = 256;  // 4 waves per workgroup
+
+template <bool VEC>
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_kernel(
+    const float *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ y, int64_t ldy, float *__restrict__ mean,
+    float *__restrict__ rstd, int64_t rows, int C, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (ROWS_BLOCK / 64);
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float *xr = x + r * ldx;
+        float *yr = y + r * ldy;
+        float s = 0.f;
+        if (VEC) {
+            for (int c = lane * 4; c < C; c += 256) {
+                f32x4 v = *(const f32x4 *)(xr + c);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) s += xr[c];
+        }
+        const float mu = ac_wave_sum(s) * invC;
+        float q = 0.f;
+        if (VEC) {
+            for (int c = lane * 4; c < C; c += 256) {
+                f32x4 v = *(const f32x4 *)(xr + c);
+                float a = v[0] - mu, b = v[1] - mu, cc = v[2] - mu, dd = v[3] - mu;
+                q += (a * a + b * b) + (cc * cc + dd * dd);
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) {
+                float a = xr[c] - mu;
+                q += a * a;
+            }
+        }
+        const float var = ac_wave_sum(q) * invC;
+        const float rs = rsqrtf(var + eps);
+        if (lane == 0) {
+            if (mean) mean[r] = mu;
+            if (rstd) rstd[r] = rs;
+        }
+        if (VEC) {
+            for (int c = lane * 4; c < C; c += 256) {
+                f32x4 v = *(const f32x4 *)(xr + c);
+                f32x4 g = *(const f32x4 *)(gamma + c);
+                f32x4 b = *(const f32x4 *)(beta + c);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = (v[j] - mu) * rs * g[j] + b[j];
+                    o[j] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                }
+                *(f32x4 *)(yr + c) = o;
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) {
+                float t = (xr[c] - mu) * rs * gamma[c] + beta[c];
+                yr[c] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+            }
+        }
+    }
+}
+
+// dgamma/dbeta partials are accumulated per workgroup in LDS, then one global
+// atomic per (workgroup, channel).
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_kernel(
+    const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
+    int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t rows, int C,
+    int act) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [2*C]
+    for (int c = threadIdx.x; c < 2 * C; c += ROWS_BLOCK) sacc[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (ROWS_BLOCK / 64);
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float *xr = x + r * ldx;
+        const float *dyr = dy + r * lddy;
+        float *dxr = dx + r * lddx;
+        const float mu = mean[r], rs = rstd[r];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float xh = (xr[c] - mu) * rs;
+            float d = dyr[c];
+            if (act == AC_ACT_GELU) d *= ac_gelu_grad(xh * gamma[c] + beta[c]);
+            float g = d * gamma[c];
+            s1 += g;
+            s2 += g * xh;
+            atomicAdd(&sacc[c], d * xh);  // ds_add_f32
+            atomicAdd(&sacc[C + c], d);
+        }
+        const float c1 = ac_wave_sum(s1) * invC;
+        const float c2 = ac_wave_sum(s2) * invC;
+        for (int c = lane; c < C; c += 64) {
+            float xh = (xr[c] - mu) * rs;
+            float d = dyr[c];
+            if (act == AC_ACT_GELU) d *= ac_gelu_grad(xh * gamma[c] + beta[c]);
+            float g = d * gamma[c];
+            dxr[c] = rs * (g - c1 - xh * c2);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += ROWS_BLOCK) {
+        if (dgamma) atomicAdd(&dgamma[c], sacc[c]);
+        if (dbeta) atomicAdd(&dbeta[c], sacc[C + c]);
+    }
+}
+
+// out[n] (+)= sum_m x[m, n]; a workgroup owns a slab of rows and all columns.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int64_t ldx,
+                                                     float *__restrict__ out, int64_t rows,
+                                                     int cols, int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += x[r * ldx + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
+__global__ __launch_bounds__(ROWS_BLOCK) void l2norm_fwd_kernel(const float *__restrict__ x,
+                                                                float *__restrict__ y,
+                                                                float *__restrict__ norm,
+                                                                int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float *xr = x + r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c] * xr[c];
+    const float nrm = sqrtf(ac_wave_sum(s));
+    if (lane == 0) norm[r] = nrm;
+    const float inv = 1.0f / nrm;
+    for (int c = lane; c < C; c += 64) y[r * C + c] = xr[c] * inv;
+}
+
+// y = x/n  =>  dx = (dy - y * (dy . y)) / n
+__global__ __launch_bounds__(ROWS_BLOCK) void l2norm_bwd_kernel(const float *__restrict__ dy,
+                                                                const float *__restrict__ y,
+                                                                const float *__restrict__ norm,
+                                                                float *__restrict__ dx,
+                                                                int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += dy[r * C + c] * y[r * C + c];
+    const float dot = ac_wave_sum(s);
+    const float inv = 1.0f / norm[r];
+    for (int c = lane; c < C; c += 64) dx[r * C + c] = (dy[r * C + c] - y[r * C + c] * dot) * inv;
+}
+
+__global__ __launch_bounds__(ROWS_BLOCK) void softmax_fwd_kernel(const float *__restrict__ x,
+                                                                 float *__restrict__ y,
+                                                                 int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[r * C + c]);
+    m = ac_wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[r * C + c] - m);
+    s = ac_wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < C; c += 64) y[r * C + c] = expf(x[r * C + c] - m) * inv;
+}
+
+// One thread per sample (C <= 32 classes).  loss is the batch mean.
+constexpr int LOSS_MAXC = 32;
+__global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ logits,
+                                                   const void *__restrict__ target,
+                                                   const float *__restrict__ alpha,
+                                                   float *__restrict__ loss,
+                                                   float *__restrict__ dlogits, int B, int C,
+                                                   int kind, float gamma, float eps) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float lb = 0.f;
+    if (b < B) {
+        float z[LOSS_MAXC], y[LOSS_MAXC];
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            z[c] = logits[(int64_t)b * C + c];
+            m = fmaxf(m, z[c]);
+        }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+        const float lse = m + logf(s);
+        const float invB = 1.0f / (float)B;
+        if (kind == 0) {
+            const float *t = (const float *)target + (int64_t)b * C;
+            float ysum = 0.f;
+            for (int c = 0; c < C; ++c) {
+                y[c] = t[c];
+                ysum += y[c];
+                lb -= y[c] * (z[c] - lse);
+            }
+            for (int c = 0; c < C; ++c)
+                dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) * ysum - y[c]) * invB;
+        } else if (kind == 1) {
+            const int t = (int)((const int64_t *)target)[b];
+            lb = -(z[t] - lse);
+            for (int c = 0; c < C; ++c)
+                dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * invB;
+        } else {
+            const int t = (int)((const int64_t *)target)[b];
+            float gsum = 0.f;
+            float g[LOSS_MAXC];
+            for (int c = 0; c < C; ++c) {
+                const float logp = z[c] - lse;
+                const float p = expf(logp);
+                float yc = eps > 0.f ? (c == t ? 1.f - eps : eps / (float)(C - 1))
+                                     : (c == t ? 1.f : 0.f);
+                const float a = alpha ? alpha[c] : 1.f;
+                const float om = fmaxf(1.f - p, 0.f);
+                float fw, dfw;  // (1-p)^gamma and gamma*(1-p)^(gamma-1)
+                if (gamma == 0.f) {
+                    fw = 1.f;
+                    dfw = 0.f;
+                } else if (gamma == 2.f) {
+                    fw = om * om;
+                    dfw = 2.f * om;
+                } else {
+                    fw = powf(om, gamma);
+                    dfw = om > 0.f ? gamma * powf(om, gamma - 1.f) : 0.f;
+                }
+                lb -= yc * a * fw * logp;
+                g[c] = yc * a * (fw - dfw * p * logp);
+                gsum += g[c];
+                y[c] = p;
+            }
+            for (int c = 0; c < C; ++c)
+                dlogits[(int64_t)b * C + c] = -(g[c] - y[c] * gsum) * invB;
+        }
+        lb *= invB;
+    }
+    lb = ac_wave_sum(lb);
+    if ((threadIdx.x & 63) == 0 && lb != 0.f) atomicAdd(loss, lb);
+}
+
+inline int grid_for_rows(int64_t rows, int rows_per_block, int cap) {
+    int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
+                                const float *beta, float *y, int64_t ldy, float *mean,
+                                float *rstd, int64_t rows, int32_t C, float eps, int32_t act,
+                                ac_stream_t stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || C <= 0) return AC_EINVAL;
+    if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
+    if (rows == 0) return AC_OK;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ac_aligned16(x) &&
+                     ac_aligned16(y) && ac_aligned16(gamma) && ac_aligned16(beta);
+    const int grid = grid_for_rows(rows, ROWS_BLOCK / 64, 256 * 16);
+    if (vec)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(grid), dim3(ROWS_BLOCK), 0,
+                           (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C,
+                           eps, act);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(grid), dim3(ROWS_BLOCK), 0,
+                           (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C,
+                           eps, act);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
+                                const float *mean, const float *rstd, const float *gamma,
+                                const float *beta, float *dx, int64_t lddx, float *dgamma,
+                                float *dbeta, int64_t rows, int32_t C, int32_t act,
+                                ac_stream_t stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || rows < 0 || C <= 0) return AC_EINVAL;
+    if (act == AC_ACT_GELU && !beta) return AC_EINVAL;
+    if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
+    if (C > 8192) return AC_EINVAL;  // 2*C floats of LDS
+    if (rows == 0) return AC_OK;
+    const int grid = grid_for_rows(rows, 64, 1024);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_BLOCK),
+                       2 * (size_t)C * sizeof(float), (hipStream_t)stream, dy, lddy, x, ldx, mean,
+                       rstd, gamma, beta, dx, lddx, dgamma, dbeta, rows, C, act);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
+                         int32_t accumulate, ac_stream_t stream) {
+    if (!x || !out || rows < 0 || cols <= 0) return AC_EINVAL;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    if (rows == 0) return AC_OK;
+    int rpb = 128;
+    while ((rows + rpb - 1) / rpb > 8192) rpb *= 2;
+    const int grid = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, out,
+                       rows, cols, rpb);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_l2norm_fwd(const float *x, float *y, float *norm, int64_t rows, int32_t C,
+                             ac_stream_t stream) {
+    if (!x || !y || !norm || rows <= 0 || C <= 0) return AC_EINVAL;
+    const int grid = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid), dim3(ROWS_BLOCK), 0, (hipStream_t)stream, x,
+                       y, norm, rows, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_l2norm_bwd(const float *dy, const float *y, const float *norm, float *dx,
+                             int64_t rows, int32_t C, ac_stream_t stream) {
+    if (!dy || !y || !norm || !dx || rows <= 0 || C <= 0) return AC_EINVAL;
+    const int grid = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(ROWS_BLOCK), 0, (hipStream_t)stream, dy,
+                       y, norm, dx, rows, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_softmax_fwd(const float *x, float *y, int64_t rows, int32_t C,
+                              ac_stream_t stream) {
+    if (!x || !y || rows <= 0 || C <= 0) return AC_EINVAL;
+    const int grid = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid), dim3(ROWS_BLOCK), 0, (hipStream_t)stream, x,
+                       y, rows, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha,
+                               float *loss, float *dlogits, int32_t B, int32_t C, int32_t kind,
+                               float gamma, float eps, ac_stream_t stream) {
+    if (!logits || !target || !loss || !dlogits || B <= 0 || C <= 0 || C > LOSS_MAXC)
+        return AC_EINVAL;
+    if (kind < 0 || kind > 2) return AC_EINVAL;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return -(int)e - 2000;
+    hipLaunchKernelGGL(loss_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       logits, target, alpha, loss, dlogits, B, C, kind, gamma, eps);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}

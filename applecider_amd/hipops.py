@@ -1,0 +1,937 @@
+"""torch.autograd.Function wrappers over the C ABI (include/applecider_hip.h).
+
+Every function here launches hand-written HIP kernels from libapplecider_hip.so on
+the current HIP stream with raw device pointers.  There is no CPU or ATen fallback:
+tensors must be fp32 GPU tensors.  PyTorch is used for memory, streams and autograd
+bookkeeping only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import (ACT_CODES, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AC_GEMM_NN,
+                   AC_GEMM_NT, AC_GEMM_TN, AdamSeg, GemmDesc, Mat, RowMap)
+
+_MATH = _lib.MATH_F32
+
+
+def set_math(mode: str):
+    """'f32' (exact fp32 matrix cores) or 'bf16' (bf16 MFMA inputs, fp32 accumulate/storage)."""
+    global _MATH
+    _MATH = {"f32": _lib.MATH_F32, "bf16": _lib.MATH_BF16}[mode]
+
+
+def get_math() -> str:
+    return "bf16" if _MATH == _lib.MATH_BF16 else "f32"
+
+
+# --------------------------------------------------------------------------- helpers
+def _lib_():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: applecider_amd kernels need a GPU tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor], elem_off: int = 0):
+    if t is None:
+        return None
+    return t.data_ptr() + elem_off * t.element_size()
+
+
+def rowmap(s3=0, r1=0, r2=0, s1=0, s2=0) -> RowMap:
+    return RowMap(int(r1), int(r2), int(s1), int(s2), int(s3))
+
+
+def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) -> Mat:
+    return Mat(ptr, rowmap(s3, r1, r2, s1, s2), _p(goff))
+
+
+def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
+         ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
+         accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None):
+    d = GemmDesc()
+    d.mode, d.math = mode, (_MATH if math is None else math)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.act, d.dact, d.accumulate = act, dact, accumulate
+    d.split_k, d.force_simple, d.alpha = int(split_k), force_simple, alpha
+    d.a, d.b, d.c = a, b, c
+    d.bias = _p(bias)
+    d.pre_out, d.ld_pre = _p(pre_out), ld_pre
+    d.aux, d.ld_aux = _p(aux), ld_aux
+    d.colscale = _p(colscale)
+    d.residual, d.ld_res = _p(residual), ld_res
+    _lib.check(_lib_().ac_gemm(C.byref(d), _stream()), "ac_gemm")
+
+
+def _split_for(m_out: int, n_out: int, k_red: int) -> int:
+    tiles = -(-m_out // 128) * -(-n_out // 128)
+    nkt = -(-k_red // 32)
+    return max(1, min(1024 // max(tiles, 1), nkt // 16))
+
+
+_seed_counter = itertools.count(1)
+
+
+def next_seed() -> int:
+    """Fresh dropout seed derived from torch's global seed (deterministic per process)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) \
+        & 0xFFFFFFFFFFFFFFFF
+
+
+_table_cache: dict = {}
+
+
+def _table(key, builder, device):
+    k = (key, str(device))
+    t = _table_cache.get(k)
+    if t is None:
+        t = torch.tensor(builder(), dtype=torch.int32, device=device)
+        _table_cache[k] = t
+    return t
+
+
+def colsum(x2d_ptr, ld, rows, cols, device) -> torch.Tensor:
+    out = torch.empty(cols, device=device, dtype=torch.float32)
+    _lib.check(_lib_().ac_colsum(x2d_ptr, ld, _p(out), rows, cols, 0, _stream()), "ac_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------- Linear
+class _Linear(Function):
+    """y = act(x @ w.T + b) [* colscale] [+ residual]   (nn.Linear + fused epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, residual, colscale):
+        x = _chk(x, "x")
+        w = _chk(w, "w")
+        N, K = w.shape
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        need_grad = any(ctx.needs_input_grad)
+        if residual is not None:
+            residual = _chk(residual, "residual").reshape(M, N)
+            if act not in (ACT_NONE, ACT_GELU, ACT_RELU):
+                raise ValueError("residual epilogue supports act none/gelu/relu only")
+        save_pre = need_grad and (act == ACT_GELU or (act == ACT_RELU and residual is not None)
+                                  or colscale is not None)
+        pre = torch.empty_like(y) if save_pre else None
+        gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
+             pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N)
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.shape_x = x.shape
+        ctx.has_b = b is not None
+        aux = pre if save_pre else (y if act != ACT_NONE else None)
+        ctx.save_for_backward(x2, w, aux, colscale)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, aux, colscale = ctx.saved_tensors
+        N, K = w.shape
+        M = x2.shape[0]
+        dy2 = _chk(dy, "dy").reshape(M, N)
+        dcs = None
+        g = dy2
+        if colscale is not None:
+            # y = pre*gamma (+res): dpre = dy*gamma ; dgamma = sum_m dy*pre
+            g = torch.empty_like(dy2)
+            dcs = torch.zeros_like(colscale)
+            _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), _p(dcs), M,
+                                                 N, _stream()), "ac_layerscale_bwd")
+        elif ctx.act != ACT_NONE:
+            g = torch.empty_like(dy2)
+            _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
+                       "ac_act_bwd")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
+            dx = dx.reshape(ctx.shape_x)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
+            gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
+                 accumulate=2, split_k=_split_for(N, K, M))
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(_p(g), N, M, N, dy.device)
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, None, dres, dcs
+
+
+def linear(x, w, b=None, act=None, residual=None, colscale=None):
+    return _Linear.apply(x, w, b, ACT_CODES[act] if not isinstance(act, int) else act, residual,
+                         colscale)
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        x = _chk(x, "x")
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_layernorm_fwd(_p(x), Cn, _p(gamma), _p(beta), _p(y), Cn, _p(mean),
+                                            _p(rstd), rows, Cn, eps, act, _stream()),
+                   "ac_layernorm_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(beta)
+        _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
+                                            _p(beta), _p(dx), Cn, _p(dg), _p(db), rows, Cn,
+                                            ctx.act, _stream()), "ac_layernorm_bwd")
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, act=None):
+    return _LayerNorm.apply(x, gamma, beta, float(eps), ACT_CODES[act])
+
+
+# --------------------------------------------------------------------------- elementwise
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _chk(x, "x")
+        y = torch.empty_like(x)
+        _lib.check(_lib_().ac_dropout(_p(x), _p(y), x.numel(), p, seed, 0, _stream()), "ac_dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(dy)
+        _lib.check(_lib_().ac_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, 0, _stream()),
+                   "ac_dropout")
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), next_seed())
+
+
+class _Gate(Function):
+    """out = a*g (+ s)."""
+
+    @staticmethod
+    def forward(ctx, a, g, s):
+        a, g = _chk(a, "a"), _chk(g, "g")
+        s = _chk(s, "s") if s is not None else None
+        out = torch.empty_like(a)
+        _lib.check(_lib_().ac_gate_fwd(_p(a), _p(g), _p(s), _p(out), a.numel(), _stream()),
+                   "ac_gate_fwd")
+        ctx.has_s = s is not None
+        ctx.save_for_backward(a, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, g = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        da, dg = torch.empty_like(a), torch.empty_like(g)
+        _lib.check(_lib_().ac_gate_bwd(_p(dout), _p(a), _p(g), _p(da), _p(dg), a.numel(),
+                                       _stream()), "ac_gate_bwd")
+        return da, dg, (dout if ctx.has_s else None)
+
+
+def gate(a, g, s=None):
+    return _Gate.apply(a, g, s)
+
+
+def gather_cols(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """dst[:, j] = src[:, idx[j]] (no gradient: the source is input metadata)."""
+    src = _chk(src, "src")
+    rows, ld = src.shape
+    n = idx.numel()
+    dst = torch.empty(rows, n, device=src.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_gather_cols(_p(src), ld, _p(idx), _p(dst), n, rows, n, _stream()),
+               "ac_gather_cols")
+    return dst
+
+
+class _Cat(Function):
+    """torch.cat(tensors, dim=1) for 2-D fp32 tensors."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_chk(t, "cat input") for t in ts]
+        rows = ts[0].shape[0]
+        widths = [t.shape[1] for t in ts]
+        total = sum(widths)
+        out = torch.empty(rows, total, device=ts[0].device, dtype=torch.float32)
+        off = 0
+        for t, wd in zip(ts, widths):
+            _lib.check(_lib_().ac_copy2d(_p(t), wd, _p(out, off), total, rows, wd, _stream()),
+                       "ac_copy2d")
+            off += wd
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _chk(dout, "dout")
+        rows, total = dout.shape
+        grads, off = [], 0
+        for wd in ctx.widths:
+            g = torch.empty(rows, wd, device=dout.device, dtype=torch.float32)
+            _lib.check(_lib_().ac_copy2d(_p(dout, off), total, _p(g), wd, rows, wd, _stream()),
+                       "ac_copy2d")
+            grads.append(g)
+            off += wd
+        return tuple(grads)
+
+
+def cat_cols(tensors: Sequence[torch.Tensor]):
+    return _Cat.apply(*tensors)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        y = torch.empty_like(a)
+        _lib.check(_lib_().ac_add(_p(a), _p(b), _p(y), a.numel(), alpha, _stream()), "ac_add")
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.alpha == 1.0:
+            return dy, dy, None
+        dy = _chk(dy, "dy")
+        g = torch.empty_like(dy)
+        # g = (dy + 0*dy) * alpha  ==  dy * alpha   (reuse the add kernel: a + a scaled by alpha/2)
+        _lib.check(_lib_().ac_add(_p(dy), _p(dy), _p(g), dy.numel(), ctx.alpha * 0.5, _stream()),
+                   "ac_add")
+        return g, g, None
+
+
+def add(a, b, alpha=1.0):
+    return _Add.apply(a, b, float(alpha))
+
+
+class _MoETop2(Function):
+    @staticmethod
+    def forward(ctx, scores, expert_out):
+        scores, expert_out = _chk(scores, "scores"), _chk(expert_out, "expert_out")
+        B, E = scores.shape
+        Cn = expert_out.shape[-1]
+        out = torch.empty(B, Cn, device=scores.device, dtype=torch.float32)
+        sel = torch.empty(B, 2, device=scores.device, dtype=torch.int32)
+        _lib.check(_lib_().ac_moe_top2_fwd(_p(scores), _p(expert_out), _p(out), _p(sel), B, E, Cn,
+                                           _stream()), "ac_moe_top2_fwd")
+        ctx.save_for_backward(scores, expert_out, sel)
+        ctx.mark_non_differentiable(sel)
+        return out, sel
+
+    @staticmethod
+    def backward(ctx, dout, _dsel):
+        scores, eo, sel = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B, E = scores.shape
+        Cn = eo.shape[-1]
+        ds, deo = torch.empty_like(scores), torch.empty_like(eo)
+        _lib.check(_lib_().ac_moe_top2_bwd(_p(dout), _p(scores), _p(eo), _p(sel), _p(ds), _p(deo),
+                                           B, E, Cn, _stream()), "ac_moe_top2_bwd")
+        return ds, deo
+
+
+def moe_top2(scores, expert_out):
+    """scores [B,E], expert_out [E,B,C] -> (out [B,C], sel [B,2])."""
+    return _MoETop2.apply(scores, expert_out)
+
+
+class _Stack(Function):
+    """torch.stack(tensors, 0) for equally shaped 2-D tensors ([B,C] x E -> [E,B,C])."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_chk(t, "stack input") for t in ts]
+        B, Cn = ts[0].shape
+        out = torch.empty(len(ts), B, Cn, device=ts[0].device, dtype=torch.float32)
+        for e, t in enumerate(ts):
+            _lib.check(_lib_().ac_copy2d(_p(t), Cn, _p(out, e * B * Cn), Cn, B, Cn, _stream()),
+                       "ac_copy2d")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return tuple(dout.unbind(0))
+
+
+def stack0(tensors):
+    return _Stack.apply(*tensors)
+
+
+class _L2Norm(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        rows, Cn = x.shape
+        y = torch.empty_like(x)
+        nrm = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_l2norm_fwd(_p(x), _p(y), _p(nrm), rows, Cn, _stream()),
+                   "ac_l2norm_fwd")
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(dy)
+        _lib.check(_lib_().ac_l2norm_bwd(_p(dy), _p(y), _p(nrm), _p(dx), y.shape[0], y.shape[1],
+                                         _stream()), "ac_l2norm_bwd")
+        return dx
+
+
+def l2_normalize(x):
+    return _L2Norm.apply(x)
+
+
+def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """Inference-only softmax over the last dim (use_probabilities)."""
+    x = _chk(x.detach(), "x")
+    y = torch.empty_like(x)
+    Cn = x.shape[-1]
+    _lib.check(_lib_().ac_softmax_fwd(_p(x), _p(y), x.numel() // Cn, Cn, _stream()),
+               "ac_softmax_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------- image branch
+def stem_patchify(img: torch.Tensor):
+    """NCHW image -> ([B*OH*OW, 64] patches, OH, OW).  No gradient (network input)."""
+    img = _chk(img, "image")
+    B, Cin, H, W = img.shape
+    OH, OW = (H - 4) // 4 + 1, (W - 4) // 4 + 1
+    patches = torch.empty(B * OH * OW, 64, device=img.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_stem_patchify(_p(img), _p(patches), B, Cin, H, W, _stream()),
+               "ac_stem_patchify")
+    return patches, OH, OW
+
+
+class _DWConv7(Function):
+    """x [B,H,W,C] NHWC, w [49,C], b [C]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _chk(x, "x"), _chk(w, "w")
+        B, H, W_, Cn = x.shape
+        y = torch.empty_like(x)
+        _lib.check(_lib_().ac_dwconv7x7_fwd(_p(x), _p(w), _p(b), _p(y), B, H, W_, Cn, _stream()),
+                   "ac_dwconv7x7_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        B, H, W_, Cn = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(Cn, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_dwconv7x7_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
+                                            Cn, _stream()), "ac_dwconv7x7_bwd")
+        return dx, dw, (db if ctx.has_b else None)
+
+
+def dwconv7x7(x, w, b):
+    return _DWConv7.apply(x, w, b)
+
+
+class _PatchConv2x2(Function):
+    """2x2 stride-2 convolution on NHWC as a gather-GEMM.  w is [Cout, (ky,kx,ci)]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _chk(x, "x"), _chk(w, "w")
+        B, H, W_, Cn = x.shape
+        Cout = w.shape[0]
+        OH, OW = H // 2, W_ // 2
+        M = B * OH * OW
+        if Cn % 32:
+            raise ValueError("PatchConv2x2 needs C % 32 == 0")
+        goff = _table(("pc2", W_, Cn),
+                      lambda: [(ky * W_ + kx) * Cn + cb * 32 for ky in range(2) for kx in range(2)
+                               for cb in range(Cn // 32)], x.device)
+        amap = dict(r1=OH * OW, s1=H * W_ * Cn, r2=OW, s2=2 * W_ * Cn, s3=2 * Cn)
+        y = torch.empty(M, Cout, device=x.device, dtype=torch.float32)
+        gemm(AC_GEMM_NT, M, Cout, 4 * Cn, mat(_p(x), goff=goff, **amap), mat(_p(w), 4 * Cn),
+             mat(_p(y), Cout), bias=b)
+        ctx.save_for_backward(x, w, goff)
+        ctx.amap, ctx.has_b = amap, b is not None
+        return y.reshape(B, OH, OW, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, goff = ctx.saved_tensors
+        B, H, W_, Cn = x.shape
+        Cout = w.shape[0]
+        OH, OW = H // 2, W_ // 2
+        M = B * OH * OW
+        dy2 = _chk(dy, "dy").reshape(M, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)  # border pixels dropped by the stride get zero gradient
+            gemm(AC_GEMM_NN, M, 4 * Cn, Cout, mat(_p(dy2), Cout), mat(_p(w), 4 * Cn),
+                 mat(_p(dx), goff=goff, **ctx.amap))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy2), Cout), mat(_p(x), goff=goff, **ctx.amap),
+                 mat(_p(dw), 4 * Cn), accumulate=2, split_k=_split_for(Cout, 4 * Cn, M))
+        if ctx.has_b:
+            db = colsum(_p(dy2), Cout, M, Cout, dy.device)
+        return dx, dw, db
+
+
+def patch_conv2x2(x, w, b):
+    return _PatchConv2x2.apply(x, w, b)
+
+
+class _AvgPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        B, HW, Cn = x.shape
+        y = torch.empty(B, Cn, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_avgpool_fwd(_p(x), _p(y), B, HW, Cn, _stream()), "ac_avgpool_fwd")
+        ctx.shape = (B, HW, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, HW, Cn = ctx.shape
+        dy = _chk(dy, "dy")
+        dx = torch.empty(B, HW, Cn, device=dy.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_avgpool_bwd(_p(dy), _p(dx), B, HW, Cn, _stream()), "ac_avgpool_bwd")
+        return dx
+
+
+def avgpool_tokens(x):
+    """[B, HW, C] -> [B, C] mean over HW."""
+    return _AvgPool.apply(x)
+
+
+# --------------------------------------------------------------------------- spectra branch
+class _MaxPool4(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        B, L, Cn = x.shape
+        Lo = L // 4
+        y = torch.empty(B, Lo, Cn, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, Lo, Cn, device=x.device, dtype=torch.uint8)
+        _lib.check(_lib_().ac_maxpool4_fwd(_p(x), _p(y), Lo * Cn, _p(idx), B, L, Cn, _stream()),
+                   "ac_maxpool4_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, L, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, L, Cn = ctx.shape
+        dy = _chk(dy, "dy")
+        dx = torch.empty(B, L, Cn, device=dy.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_maxpool4_bwd(_p(dy), (L // 4) * Cn, _p(idx), _p(dx), B, L, Cn,
+                                           _stream()), "ac_maxpool4_bwd")
+        return dx
+
+
+def maxpool4(x):
+    return _MaxPool4.apply(x)
+
+
+class _GlobalMax(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        B, L, Cn = x.shape
+        y = torch.empty(B, Cn, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, Cn, device=x.device, dtype=torch.int32)
+        _lib.check(_lib_().ac_globalmax_fwd(_p(x), _p(y), _p(idx), B, L, Cn, _stream()),
+                   "ac_globalmax_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, L, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, L, Cn = ctx.shape
+        dy = _chk(dy, "dy")
+        dx = torch.empty(B, L, Cn, device=dy.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_globalmax_bwd(_p(dy), _p(idx), _p(dx), B, L, Cn, _stream()),
+                   "ac_globalmax_bwd")
+        return dx
+
+
+def global_max(x):
+    return _GlobalMax.apply(x)
+
+
+def _pad_rows(x, B, L, Cn, pad_lo, Lp):
+    y = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_pad_rows(_p(x), _p(y), B, L, Cn, pad_lo, Lp, _stream()), "ac_pad_rows")
+    return y
+
+
+class _ConvGroup1d(Function):
+    """The parallel 'same' Conv1d bank of a SpectraNetBlock (spectranet.py:18-20,25):
+    ycat[b, l, j*Cout + co] = bias_j[co] + sum_{t,ci} x[b, l + t - k_j//2, ci] * w_j[co, t, ci].
+
+    x is [B, L, Cin]; each w_j is stored tap-major as [Cout, k_j*Cin].  Implicit GEMM over
+    a zero-padded copy of x: the im2col row of (b, l) is a contiguous k_j*Cin slice, so A is
+    just an overlapping-row view (row stride Cin).  For Cin == 1 the rows would be 4-byte
+    shifted; there the 8 residues l%8 become 8 shifted copies of the filter instead
+    (Toeplitz trick) so that A rows are 32-byte strided.
+    args: x, ksizes(tuple), w0, b0, w1, b1, ...
+    """
+
+    @staticmethod
+    def forward(ctx, x, ksizes, *wb):
+        x = _chk(x, "x")
+        B, L, Cin = x.shape
+        ws = [_chk(w, "w") for w in wb[0::2]]
+        bs = list(wb[1::2])
+        nconv = len(ksizes)
+        Cout = ws[0].shape[0]
+        Ncat = nconv * Cout
+        if Cout % 32:
+            raise ValueError("ConvGroup1d needs Cout % 32 == 0")
+        for k in ksizes:
+            if k % 2 == 0:
+                raise ValueError("ConvGroup1d supports odd kernel sizes ('same' padding k//2)")
+        Pmax = max(ksizes) // 2
+        dev = x.device
+        ycat = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
+        ctx.ksizes, ctx.dims = tuple(ksizes), (B, L, Cin, Cout, Pmax)
+        ctx.has_b = [b is not None for b in bs]
+        if Cin == 1:
+            if L % 8:
+                raise ValueError("Cin == 1 path needs L % 8 == 0")
+            Lp = (L + 2 * Pmax + 48 + 3) // 4 * 4
+            xpad = _pad_rows(x, B, L, 1, Pmax, Lp)
+            Lq = L // 8
+            saved_meta = []
+            for j, k in enumerate(ksizes):
+                off = Pmax - k // 2
+                shift = off % 4
+                base = off - shift
+                Kp = (k + 7 + shift + 3) // 4 * 4
+                wexp = torch.empty(8 * Cout, Kp, device=dev, dtype=torch.float32)
+                _lib.check(_lib_().ac_toeplitz_expand(_p(ws[j]), _p(wexp), Cout, k, Kp, shift,
+                                                      _stream()), "ac_toeplitz_expand")
+                goff_c = _table(("tz", Ncat, Cout, j),
+                                lambda j=j: [r * Ncat + j * Cout + cb * 32 for r in range(8)
+                                             for cb in range(Cout // 32)], dev)
+                # bias[(r,co)] = b[co]; 8*Cout floats of plumbing
+                bexp = bs[j].detach().repeat(8) if bs[j] is not None else None
+                gemm(AC_GEMM_NT, B * Lq, 8 * Cout, Kp,
+                     mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(wexp), Kp),
+                     mat(_p(ycat), 8 * Ncat, goff=goff_c), bias=bexp)
+                saved_meta.append((base, shift, Kp, goff_c))
+            ctx.meta = saved_meta
+            ctx.Lp = Lp
+            ctx.save_for_backward(xpad, *ws)
+        else:
+            if Cin % 32:
+                raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
+            Lp = L + 2 * Pmax
+            xpad = _pad_rows(x, B, L, Cin, Pmax, Lp)
+            for j, k in enumerate(ksizes):
+                off = Pmax - k // 2
+                gemm(AC_GEMM_NT, B * L, Cout, k * Cin,
+                     mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
+                     mat(_p(ws[j]), k * Cin), mat(_p(ycat, j * Cout), Ncat), bias=bs[j])
+            ctx.Lp = Lp
+            ctx.save_for_backward(xpad, *ws)
+        return ycat
+
+    @staticmethod
+    def backward(ctx, dycat):
+        xpad, *ws = ctx.saved_tensors
+        B, L, Cin, Cout, Pmax = ctx.dims
+        ksizes = ctx.ksizes
+        nconv = len(ksizes)
+        Ncat = nconv * Cout
+        dev = dycat.device
+        dycat = _chk(dycat, "dycat")
+        Lp = ctx.Lp
+        grads = []
+        dx = None
+        if Cin == 1:
+            Lq = L // 8
+            for j, k in enumerate(ksizes):
+                base, shift, Kp, goff_c = ctx.meta[j]
+                dwexp = torch.zeros(8 * Cout, Kp, device=dev, dtype=torch.float32)
+                gemm(AC_GEMM_TN, 8 * Cout, Kp, B * Lq, mat(_p(dycat), 8 * Ncat, goff=goff_c),
+                     mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(dwexp), Kp),
+                     accumulate=2, split_k=_split_for(8 * Cout, Kp, B * Lq))
+                dw = torch.empty(Cout, k, device=dev, dtype=torch.float32)
+                _lib.check(_lib_().ac_toeplitz_fold(_p(dwexp), _p(dw), Cout, k, Kp, shift,
+                                                    _stream()), "ac_toeplitz_fold")
+                db = colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev) if ctx.has_b[j] else None
+                grads += [dw, db]
+            if ctx.needs_input_grad[0]:
+                raise NotImplementedError("input gradient of the Cin == 1 conv bank is not needed "
+                                          "on the path (the flux is a network input)")
+        else:
+            if ctx.needs_input_grad[0]:
+                Lpd = L + 2 * Pmax
+                dypad = _pad_rows(dycat, B, L, Ncat, Pmax, Lpd)
+                dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
+            for j, k in enumerate(ksizes):
+                p = k // 2
+                off = Pmax - p
+                if ctx.needs_input_grad[0]:
+                    goff = _table(("cg_dx", Ncat, Cout, j, k, Pmax),
+                                  lambda j=j, k=k, p=p: [(Pmax + p - t) * Ncat + j * Cout + cb * 32
+                                                         for t in range(k)
+                                                         for cb in range(Cout // 32)], dev)
+                    gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
+                         mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
+                         mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
+                         mat(_p(dx), Cin), accumulate=0 if j == 0 else 1)
+                dw = torch.zeros(Cout, k * Cin, device=dev, dtype=torch.float32)
+                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dycat, j * Cout), Ncat),
+                     mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
+                     mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L))
+                db = colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev) if ctx.has_b[j] else None
+                grads += [dw, db]
+        return (dx, None, *grads)
+
+
+def conv_group1d(x, ksizes, weights, biases):
+    args = []
+    for w, b in zip(weights, biases):
+        args += [w, b]
+    return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), *args)
+
+
+# --------------------------------------------------------------------------- photometry branch
+class _Embed(Function):
+    """CLS + in_proj(x) + Time2Vec(x[...,0])  (HyraxBaselineCLS.py:58-71).
+    x8 [B,L,8] (7 channels + zero pad), W8 [D,8], bias [D], tw [D], tb [D], cls [D]."""
+
+    @staticmethod
+    def forward(ctx, x8, W8, bias, tw, tb, cls):
+        x8 = _chk(x8, "x8")
+        B, L, _ = x8.shape
+        D = W8.shape[0]
+        h = torch.empty(B, L + 1, D, device=x8.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_embed_fwd(_p(x8), _p(_chk(W8)), _p(bias), _p(tw), _p(tb), _p(cls),
+                                        _p(h), B, L, D, _stream()), "ac_embed_fwd")
+        ctx.save_for_backward(x8, tw, tb)
+        ctx.dims = (B, L, D)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x8, tw, tb = ctx.saved_tensors
+        B, L, D = ctx.dims
+        dh = _chk(dh, "dh")
+        dev = dh.device
+        dW = torch.zeros(D, 8, device=dev, dtype=torch.float32)
+        db, dtw, dtb, dcls = (torch.zeros(D, device=dev, dtype=torch.float32) for _ in range(4))
+        _lib.check(_lib_().ac_embed_bwd(_p(dh), _p(x8), _p(tw), _p(tb), _p(dW), _p(db), _p(dtw),
+                                        _p(dtb), _p(dcls), B, L, D, _stream()), "ac_embed_bwd")
+        return None, dW, db, dtw, dtb, dcls
+
+
+def embed(x8, W8, bias, tw, tb, cls):
+    return _Embed.apply(x8, W8, bias, tw, tb, cls)
+
+
+class _MHA(Function):
+    @staticmethod
+    def forward(ctx, qkv, pad_u8, H, p_drop, seed):
+        qkv = _chk(qkv, "qkv")
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        Dh = D // H
+        out = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_mha_fwd(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
+                                      seed, _stream()), "ac_mha_fwd")
+        ctx.save_for_backward(qkv, pad_u8, out, lse)
+        ctx.cfg = (B, T, H, Dh, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, pad_u8, out, lse = ctx.saved_tensors
+        B, T, H, Dh, p_drop, seed = ctx.cfg
+        dout = _chk(dout, "dout")
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib_().ac_mha_bwd(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
+                                      T, H, Dh, p_drop, seed, _stream()), "ac_mha_bwd")
+        return dqkv, None, None, None, None
+
+
+def mha(qkv, pad_u8, n_heads: int, p_drop: float = 0.0, training: bool = False):
+    p = float(p_drop) if training else 0.0
+    return _MHA.apply(qkv, pad_u8, n_heads, p, next_seed() if p > 0 else 0)
+
+
+# --------------------------------------------------------------------------- losses
+class _Loss(Function):
+    @staticmethod
+    def forward(ctx, logits, target, kind, gamma, eps, alpha):
+        logits = _chk(logits, "logits")
+        B, Cn = logits.shape
+        if kind == 0:
+            target = _chk(target, "target")
+        else:
+            if target.dtype != torch.int64:
+                target = target.to(torch.int64)
+            target = target.contiguous()
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dlogits = torch.empty_like(logits)
+        _lib.check(_lib_().ac_loss_fwd_bwd(_p(logits), _p(target), _p(alpha), _p(loss), _p(dlogits),
+                                           B, Cn, kind, gamma, eps, _stream()), "ac_loss_fwd_bwd")
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        if dloss.numel() == 1 and not dloss.requires_grad:
+            # scale by the (usually 1.0) upstream gradient through the add kernel: g = d*dloss
+            scale = dloss.reshape(1)
+            g = dlogits.clone()
+            _lib.check(_lib_().ac_scale_by_dev(_p(g), g.numel(), _p(_chk(scale)), _stream()),
+                       "ac_scale_by_dev")
+            return g, None, None, None, None, None
+        raise RuntimeError("loss backward expects a scalar upstream gradient")
+
+
+def cross_entropy_soft(logits, target_prob):
+    return _Loss.apply(logits, target_prob, 0, 0.0, 0.0, None)
+
+
+def cross_entropy_index(logits, target_idx):
+    return _Loss.apply(logits, target_idx, 1, 0.0, 0.0, None)
+
+
+def focal_loss(logits, target_idx, gamma=2.0, alpha=None, eps=0.0):
+    return _Loss.apply(logits, target_idx, 2, float(gamma), float(eps), alpha)
+
+
+# --------------------------------------------------------------------------- optimizer kernels
+def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, step, grad_scale_dev=None):
+    arr = (AdamSeg * len(segs))(*segs)
+    _lib.check(_lib_().ac_adam_flat(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), arr,
+                                    len(segs), step, _p(grad_scale_dev), _stream()),
+               "ac_adam_flat")
+
+
+def sgd_flat(param, grad, buf, lr, momentum, weight_decay, first_step):
+    _lib.check(_lib_().ac_sgd_flat(_p(param), _p(grad), _p(buf), param.numel(), lr, momentum,
+                                   weight_decay, int(first_step), _stream()), "ac_sgd_flat")
+
+
+def clip_coef(grad_flat, max_norm: float):
+    """Device-side clip coefficient min(1, max_norm/(||g||+1e-6)); returns (coef, sumsq)."""
+    sumsq = torch.empty(1, device=grad_flat.device, dtype=torch.float32)
+    coef = torch.empty(1, device=grad_flat.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_sumsq(_p(grad_flat), grad_flat.numel(), _p(sumsq), _stream()), "ac_sumsq")
+    _lib.check(_lib_().ac_clip_coef(_p(sumsq), float(max_norm), _p(coef), _stream()),
+               "ac_clip_coef")
+    return coef, sumsq
+
+
+# --------------------------------------------------------------------------- misc
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _chk(x, "x")
+        y = torch.empty_like(x)
+        _lib.check(_lib_().ac_act_fwd(_p(x), _p(y), x.numel(), kind, _stream()), "ac_act_fwd")
+        ctx.kind = kind
+        ctx.save_for_backward(x if kind in (ACT_GELU, ACT_RELU) else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (aux,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(dy)
+        _lib.check(_lib_().ac_act_bwd(_p(dy), _p(aux), _p(dx), dy.numel(), ctx.kind, _stream()),
+                   "ac_act_bwd")
+        return dx, None
+
+
+def activation(x, kind: str):
+    return _Act.apply(x, ACT_CODES[kind])
+
+
+class _TakeToken(Function):
+    """z[:, idx, :] of a [B, T, D] tensor as a contiguous [B, D] tensor."""
+
+    @staticmethod
+    def forward(ctx, z, idx):
+        z = _chk(z, "z")
+        B, T, D = z.shape
+        out = torch.empty(B, D, device=z.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_copy2d(_p(z, idx * D), T * D, _p(out), D, B, D, _stream()),
+                   "ac_copy2d")
+        ctx.cfg = (B, T, D, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D, idx = ctx.cfg
+        dout = _chk(dout, "dout")
+        dz = torch.zeros(B, T, D, device=dout.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_copy2d(_p(dout), D, _p(dz, idx * D), T * D, B, D, _stream()),
+                   "ac_copy2d")
+        return dz, None
+
+
+def take_token(z, idx: int = 0):
+    return _TakeToken.apply(z, int(idx))
+
+
+def pad_channels(x: torch.Tensor, width: int) -> torch.Tensor:
+    """[..., C] -> [..., width] zero padded (network inputs only; no gradient)."""
+    x = _chk(x, "x")
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    out = torch.zeros(*x.shape[:-1], width, device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_copy2d(_p(x), Cn, _p(out), width, rows, Cn, _stream()), "ac_copy2d")
+    return out

@@ -1,0 +1,289 @@
+/*
+ * applecider_hip.h — C ABI of libapplecider_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary of the AppleCiDEr forward/backward hot path
+ * (SURVEY.md §8b).  The reference (skyportal/applecider) is pure Python and has
+ * no FFI of its own: every entry point below replaces the stock ATen op(s) that
+ * the cited reference lines dispatch to.  The Python host modules under
+ * applecider_amd/models call these through ctypes from
+ * torch.autograd.Function.forward/backward.
+ *
+ * Conventions (all entry points):
+ *   - extern "C"; plain pointers and sizes; no torch types.
+ *   - every pointer is a caller-owned DEVICE pointer (tensor.data_ptr()) that
+ *     must stay alive until the stream work has finished; fp32 unless stated.
+ *   - last argument is the hipStream_t to launch on (passed as void*).
+ *   - returns 0 on success, a negative AC_E* code on bad arguments, or the
+ *     negated hipError_t of a failed launch.  Never allocates, never
+ *     synchronises, keeps no global mutable state (re-entrant).
+ *   - "ld*" arguments are leading dimensions in ELEMENTS.
+ */
+#ifndef APPLECIDER_HIP_H
+#define APPLECIDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_ABI_VERSION 1
+
+#define AC_OK 0
+#define AC_EINVAL (-22)     /* bad argument / unsupported shape            */
+#define AC_EALIGN (-1001)   /* pointer / stride alignment requirement unmet */
+#define AC_ELAUNCH (-1002)  /* generic launch failure                       */
+
+typedef void *ac_stream_t; /* hipStream_t */
+
+int ac_abi_version(void);
+const char *ac_strerror(int code);
+
+/* ------------------------------------------------------------------------
+ * Gather-GEMM on the matrix cores.
+ *
+ * One kernel family carries every dense contraction of the path:
+ *   nn.Linear            astrominn.py:23-35,46-58,133-139; HyraxBaselineCLS.py:19,38;
+ *                        spectranet.py:138-155
+ *   nn.Conv1d (k up to 1021, implicit GEMM over a zero-padded [B,Lp,C] buffer)
+ *                        spectranet.py:18-20,25 (C1)
+ *   ConvNeXt 1x1 / 2x2-s2 / 4x4-s4 convolutions (timm convnext_tiny, A2)
+ *   transformer QKV / out / FFN projections (nn.TransformerEncoderLayer, B2)
+ * and their dX / dW backward products.
+ *
+ * A matrix operand is described by an "outer" index (a row of memory) and an
+ * "inner" index (the contiguous direction):
+ *     elem(outer o, inner i) = ptr + rowaddr(o) + (goff ? goff[i/32] + i%32 : i)
+ *     rowaddr(o) = r1 == 0 ? o*s3
+ *                          : (o/r1)*s1 + ((o%r1)/r2)*s2 + (o%r2)*s3
+ * which expresses plain strided matrices, overlapping-row (Toeplitz) views of
+ * a padded sequence (conv1d), and 2x2 patch gathers (ConvNeXt downsample).
+ * All strides and goff entries must be multiples of 4 elements (16 B).
+ *
+ * mode AC_GEMM_NT : C[m,n] = sum_k A[m,k] * B[n,k]   A outer=m inner=k, B outer=n inner=k
+ * mode AC_GEMM_NN : C[m,n] = sum_k A[m,k] * B[k,n]   A outer=m inner=k, B outer=k inner=n
+ * mode AC_GEMM_TN : C[m,n] = sum_k A[k,m] * B[k,n]   A outer=k inner=m, B outer=k inner=n
+ * C: outer=m inner=n (same addressing scheme, so results can be scattered).
+ *
+ * Epilogue, per element, in this order:
+ *   v = alpha*acc (+ bias[n]); if pre_out: pre_out[m,n] = v; v = act(v);
+ *   if dact: v *= act'(aux[m,n]); if colscale: v *= colscale[n];
+ *   if residual: v += residual[m,n];
+ *   accumulate: 0 store, 1 C += v, 2 atomicAdd(C, v)  (2 is forced by split_k > 1).
+ * ---------------------------------------------------------------------- */
+enum { AC_GEMM_NT = 0, AC_GEMM_NN = 1, AC_GEMM_TN = 2 };
+enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC_ACT_TANH = 4 };
+/* dact: derivative taken from aux.  GELU/RELU expect the PRE-activation in aux,
+ * SIGMOID/TANH expect the activation OUTPUT in aux. */
+enum { AC_MATH_F32 = 0, AC_MATH_BF16 = 1 }; /* MFMA input type; storage is fp32 */
+
+typedef struct ac_rowmap {
+    int32_t r1, r2;
+    int64_t s1, s2, s3;
+} ac_rowmap;
+
+typedef struct ac_mat {
+    const void *ptr;
+    ac_rowmap rows;
+    const int32_t *goff; /* nullable; one entry per 32 inner elements */
+} ac_mat;
+
+typedef struct ac_gemm_desc {
+    int32_t mode;
+    int32_t math;
+    int32_t M, N, K;
+    int32_t act;
+    int32_t dact;
+    int32_t accumulate;
+    int32_t split_k;      /* >= 1 */
+    int32_t force_simple; /* 1: use the scalar reference kernel (tests) */
+    float alpha;
+    int32_t _pad0;
+    ac_mat a, b, c;
+    const float *bias;
+    float *pre_out;
+    int64_t ld_pre;
+    const float *aux;
+    int64_t ld_aux;
+    const float *colscale;
+    const float *residual;
+    int64_t ld_res;
+} ac_gemm_desc;
+
+int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Row-wise LayerNorm over the last dimension (nn.LayerNorm: astrominn.py:25,34,47,52;
+ * spectranet.py:21,31; HyraxBaselineCLS.py:34 and the two norms inside each
+ * nn.TransformerEncoderLayer; timm ConvNeXt block norm / LayerNorm2d in NHWC).
+ * act = AC_ACT_GELU fuses the GELU of spectranet.py:35 (y = gelu(ln(x))).
+ * bwd accumulates dgamma/dbeta with atomics: zero them first.
+ * ---------------------------------------------------------------------- */
+int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
+                     float *y, int64_t ldy, float *mean, float *rstd, int64_t rows, int32_t C,
+                     float eps, int32_t act, ac_stream_t stream);
+int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
+                     const float *mean, const float *rstd, const float *gamma, const float *beta,
+                     float *dx, int64_t lddx, float *dgamma, float *dbeta, int64_t rows,
+                     int32_t C, int32_t act, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Elementwise / reduction helpers.
+ * ---------------------------------------------------------------------- */
+/* out[n] (+)= sum_m x[m,n]  — bias gradients. */
+int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
+              int32_t accumulate, ac_stream_t stream);
+/* out = dy * act'(aux)  (kinds as in ac_gemm dact); in-place allowed. */
+int ac_act_bwd(const float *dy, const float *aux, float *out, int64_t n, int32_t kind,
+               ac_stream_t stream);
+/* y = act(x) elementwise. */
+int ac_act_fwd(const float *x, float *y, int64_t n, int32_t kind, ac_stream_t stream);
+/* 2-D strided copy: dst[r, c] = src[r, c]. */
+int ac_copy2d(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows,
+              int32_t cols, ac_stream_t stream);
+/* dst[r, j] = src[r, idx[j]]  — metadata column gathers, astrominn.py:249-261. */
+int ac_gather_cols(const float *src, int64_t lds, const int32_t *idx, float *dst, int64_t ldd,
+                   int64_t rows, int32_t ncols, ac_stream_t stream);
+/* out = a*g + s (s nullable)  — ResidualTowerBlock combine astrominn.py:62, head product :41. */
+int ac_gate_fwd(const float *a, const float *g, const float *s, float *out, int64_t n,
+                ac_stream_t stream);
+/* da = dout*g, dg = dout*a. */
+int ac_gate_bwd(const float *dout, const float *a, const float *g, float *da, float *dg,
+                int64_t n, ac_stream_t stream);
+/* y = x * keep(seed, offset + i) / (1-p); the same call with dy gives dx (nn.Dropout). */
+int ac_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
+               ac_stream_t stream);
+/* ConvNeXt layer-scale backward: dyl = dy*gamma[n]; dgamma[n] += sum_m dy*ylin (atomics). */
+int ac_layerscale_bwd(const float *dy, const float *ylin, const float *gamma, float *dyl,
+                      float *dgamma, int64_t rows, int32_t C, ac_stream_t stream);
+/* y = (a + b) * alpha. */
+int ac_add(const float *a, const float *b, float *y, int64_t n, float alpha, ac_stream_t stream);
+/* x *= s[0] * scale  (device scalar; gradient clipping). */
+int ac_scale_by_dev(float *x, int64_t n, const float *s, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Image branch (timm convnext_tiny called at astrominn.py:12-17).
+ * Activations are NHWC fp32: [B, H, W, C].
+ * ---------------------------------------------------------------------- */
+/* NCHW image -> 4x4 stride-4 patches [B*OH*OW, 64] ((ky,kx,c) order, 48 used, zero padded);
+ * OH = (H-4)/4+1.  The stem conv then is a plain GEMM. */
+int ac_stem_patchify(const float *img, float *patches, int32_t B, int32_t Cin, int32_t H,
+                     int32_t W, ac_stream_t stream);
+/* depthwise 7x7, pad 3.  w is [49, C] (tap-major), bias [C]. */
+int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y, int32_t B,
+                     int32_t H, int32_t W, int32_t C, ac_stream_t stream);
+/* dx = corr(dy, w); dw[49,C] += ..., dbias[C] += ... (atomics; zero first). */
+int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
+                     float *dbias, int32_t B, int32_t H, int32_t W, int32_t C,
+                     ac_stream_t stream);
+/* mean over the HW positions: [B, HW, C] -> [B, C]; bwd broadcasts dy/HW. */
+int ac_avgpool_fwd(const float *x, float *y, int32_t B, int32_t HW, int32_t C, ac_stream_t stream);
+int ac_avgpool_bwd(const float *dy, float *dx, int32_t B, int32_t HW, int32_t C,
+                   ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Spectra branch (spectranet.py:7-41, 163-170).  Sequences are [B, L, C].
+ * ---------------------------------------------------------------------- */
+/* MaxPool1d(4) along L; writes y[b, l/4, c] at y + b*y_bstride + (l/4)*C (so it can
+ * land inside the next stage's zero-padded buffer); idx records the argmax (0..3). */
+int ac_maxpool4_fwd(const float *x, float *y, int64_t y_bstride, uint8_t *idx, int32_t B,
+                    int32_t L, int32_t C, ac_stream_t stream);
+int ac_maxpool4_bwd(const float *dy, int64_t dy_bstride, const uint8_t *idx, float *dx,
+                    int32_t B, int32_t L, int32_t C, ac_stream_t stream);
+/* adaptive_max_pool1d(x, 1): [B, L, C] -> [B, C] with argmax. */
+int ac_globalmax_fwd(const float *x, float *y, int32_t *idx, int32_t B, int32_t L, int32_t C,
+                     ac_stream_t stream);
+int ac_globalmax_bwd(const float *dy, const int32_t *idx, float *dx, int32_t B, int32_t L,
+                     int32_t C, ac_stream_t stream);
+/* flux [B, L] -> zero-padded [B, Lp] at offset pad (stage-1 Toeplitz operand). */
+int ac_pad_rows(const float *x, float *y, int32_t B, int32_t L, int32_t C, int32_t pad_lo,
+                int32_t Lp, ac_stream_t stream);
+/* stage-1 (Cin = 1) weight expansion for the 8-phase Toeplitz GEMM:
+ *   w[Cout, k] -> wexp[8*Cout, Kp],  wexp[(r,co), t'] = w[co, t' - r - shift]  (0 elsewhere)
+ * and the matching gradient fold dw[co,t] = sum_r dwexp[(r,co), t + r + shift].
+ * Needs Kp >= k + 7 + shift. */
+int ac_toeplitz_expand(const float *w, float *wexp, int32_t Cout, int32_t k, int32_t Kp,
+                       int32_t shift, ac_stream_t stream);
+int ac_toeplitz_fold(const float *dwexp, float *dw, int32_t Cout, int32_t k, int32_t Kp,
+                     int32_t shift, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Photometry branch (HyraxBaselineCLS.py:49-86, Time2Vec.py:48-72).
+ * ---------------------------------------------------------------------- */
+/* h[b,0,:] = cls; h[b,1+l,:] = W x[b,l,:] + bias + time2vec(x[b,l,0]).
+ * x is [B, L, 8] (7 channels + one zero pad), W is [D, 8], tw/tb are [D]
+ * (tw[0]=w0, tb[0]=b0, tw[1:]=w, tb[1:]=b). */
+int ac_embed_fwd(const float *x, const float *W, const float *bias, const float *tw,
+                 const float *tb, const float *cls, float *h, int32_t B, int32_t L, int32_t D,
+                 ac_stream_t stream);
+/* dW[D,8], dbias, dtw, dtb, dcls accumulate with atomics (zero first). */
+int ac_embed_bwd(const float *dh, const float *x, const float *tw, const float *tb, float *dW,
+                 float *dbias, float *dtw, float *dtb, float *dcls, int32_t B, int32_t L,
+                 int32_t D, ac_stream_t stream);
+/* Multi-head self-attention core with key-padding mask (True/1 = ignore key).
+ * qkv is [B, T, 3*D] (q | k | v, heads contiguous inside each D), out is [B, T, D].
+ * lse [B, H, T] is saved for backward.  p_drop > 0 applies dropout to the
+ * attention probabilities with the counter RNG. */
+int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B,
+               int32_t T, int32_t H, int32_t Dh, float p_drop, uint64_t seed,
+               ac_stream_t stream);
+int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
+               const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
+               float p_drop, uint64_t seed, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Towers / MoE / fusion head (astrominn.py:264-295; _archive core/model.py:40-67).
+ * ---------------------------------------------------------------------- */
+/* scores [B,E] (sigmoid outputs), expert_out [E,B,C] -> out [B,C]; sel [B,2] int32. */
+int ac_moe_top2_fwd(const float *scores, const float *expert_out, float *out, int32_t *sel,
+                    int32_t B, int32_t E, int32_t C, ac_stream_t stream);
+int ac_moe_top2_bwd(const float *dout, const float *scores, const float *expert_out,
+                    const int32_t *sel, float *dscores, float *dexpert_out, int32_t B,
+                    int32_t E, int32_t C, ac_stream_t stream);
+/* y = x / ||x||_2 per row. */
+int ac_l2norm_fwd(const float *x, float *y, float *norm, int64_t rows, int32_t C,
+                  ac_stream_t stream);
+int ac_l2norm_bwd(const float *dy, const float *y, const float *norm, float *dx, int64_t rows,
+                  int32_t C, ac_stream_t stream);
+/* softmax over the last dim (use_probabilities, astrominn.py:297). */
+int ac_softmax_fwd(const float *x, float *y, int64_t rows, int32_t C, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Losses: one kernel computes the mean loss AND dlogits (= dloss/dlogits for mean).
+ *   kind 0: CrossEntropyLoss with class-probability targets  (astrominn.py:147,315)
+ *   kind 1: CrossEntropyLoss with int64 class indices         (brew_cider.py:1229)
+ *   kind 2: FocalLoss(gamma, alpha, eps)                      (HyraxBaselineCLS.py:169-191)
+ * loss is a single device float, zeroed by the call.
+ * ---------------------------------------------------------------------- */
+int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha, float *loss,
+                    float *dlogits, int32_t B, int32_t C, int32_t kind, float gamma, float eps,
+                    ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizers over flat fp32 buffers (torch.optim.AdamW astrominn.py:151-218,
+ * Adam HyraxBaselineCLS.py:41, SGD injected by Hyrax for SpectraNet).
+ * seg_* describe param groups as [begin,end) element ranges with their own
+ * hyper-parameters; step is the 1-based step count.
+ * ---------------------------------------------------------------------- */
+typedef struct ac_adam_seg {
+    int64_t begin, end;
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t decoupled; /* 1 = AdamW, 0 = Adam (L2 into grad) */
+} ac_adam_seg;
+/* segs is a HOST array; grad_scale_dev (nullable) is a DEVICE scalar multiplied into the
+ * gradient (the clip coefficient of ac_clip_coef), so clipping needs no host sync. */
+int ac_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                 const ac_adam_seg *segs_host, int32_t nseg, int32_t step,
+                 const float *grad_scale_dev, ac_stream_t stream);
+int ac_sgd_flat(float *param, const float *grad, float *momentum_buf, int64_t n, float lr,
+                float momentum, float weight_decay, int32_t first_step, ac_stream_t stream);
+/* out[0] = sum x^2 (zeroed by the call); clip coefficient computed on device:
+ * coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)). */
+int ac_sumsq(const float *x, int64_t n, float *out, ac_stream_t stream);
+int ac_clip_coef(const float *sumsq, float max_norm, float *coef, ac_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APPLECIDER_HIP_H */

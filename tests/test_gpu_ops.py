@@ -1,0 +1,530 @@
+"""Kernel-level parity: every HIP op (through the C ABI) against the PyTorch CPU fp32 op the
+reference dispatches to.  Tolerances: fp32 MFMA path 2e-4 relative to the tensor's max (sum
+order differs), bf16-input path 2e-2."""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=2e-4, name=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, f"{name}: shape {a.shape} vs {b.shape}"
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, f"{name}: rel-to-max err {err:.3e} > {tol}"
+
+
+def g(dev, *shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=gen) * scale)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 100), (1000, 96, 384), (64, 520, 1028),
+                                   (257, 5, 64)])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+def test_gemm_modes(dev, M, N, K, mode):
+    from applecider_amd import hipops as H
+    a = g(dev, M, K, seed=1)
+    b = g(dev, N, K, seed=2)
+    ref = a @ b.t()
+    ad, bd = a.to(dev), b.to(dev)
+    c = torch.empty(M, N, device=dev)
+    if mode == "NT":
+        H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c), N))
+    elif mode == "NN":
+        bt = bd.t().contiguous()  # [K, N]
+        H.gemm(H.AC_GEMM_NN, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bt), N), H.mat(H._p(c), N))
+    else:
+        at = ad.t().contiguous()  # [K, M]
+        bt = bd.t().contiguous()
+        if M % 4 or N % 4:
+            pytest.skip("TN MFMA path needs M,N % 4 == 0 (falls to scalar kernel, covered below)")
+        H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(at), M), H.mat(H._p(bt), N), H.mat(H._p(c), N))
+    torch.cuda.synchronize()
+    close(c, ref, name=f"gemm {mode}")
+
+
+def test_gemm_simple_matches_mfma(dev):
+    from applecider_amd import hipops as H
+    M, N, K = 200, 136, 96
+    a, b = g(dev, M, K, seed=3).to(dev), g(dev, N, K, seed=4).to(dev)
+    c1, c2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a), K), H.mat(H._p(b), K), H.mat(H._p(c1), N))
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a), K), H.mat(H._p(b), K), H.mat(H._p(c2), N),
+           force_simple=1)
+    close(c1, c2, tol=1e-5, name="mfma vs scalar")
+    # exact-integer check with asymmetric operands (catches transposed fragment maps)
+    ai = torch.arange(M * K).reshape(M, K).remainder(7).float() - 3
+    bi = torch.arange(N * K).reshape(N, K).remainder(5).float() - 2
+    c3 = torch.empty(M, N, device=dev)
+    ad, bd = ai.to(dev), bi.to(dev)
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c3), N))
+    assert torch.equal(c3.cpu(), ai @ bi.t())
+
+
+def test_gemm_epilogue_splitk_bf16(dev):
+    from applecider_amd import hipops as H
+    M, N, K = 512, 256, 2048
+    a, b = g(dev, M, K, seed=5), g(dev, N, K, seed=6)
+    bias, res, cs = g(dev, N, seed=7), g(dev, M, N, seed=8), g(dev, N, seed=9)
+    ad, bd = a.to(dev), b.to(dev)
+    c = torch.empty(M, N, device=dev)
+    pre = torch.empty(M, N, device=dev)
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c), N),
+           bias=bias.to(dev), act=H.ACT_GELU, pre_out=pre, ld_pre=N, colscale=cs.to(dev),
+           residual=res.to(dev), ld_res=N)
+    lin = a @ b.t() + bias
+    close(pre, lin, name="pre_out")
+    close(c, F.gelu(lin) * cs + res, name="epilogue")
+    # split-K with atomics
+    c2 = torch.zeros(M, N, device=dev)
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c2), N),
+           accumulate=2, split_k=8)
+    close(c2, a @ b.t(), name="split-k")
+    # bf16 matrix-core path (inputs rounded to bf16)
+    for mode in ("NT", "NN", "TN"):
+        c3 = torch.empty(M, N, device=dev)
+        if mode == "NT":
+            H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K),
+                   H.mat(H._p(c3), N), math=1)
+        elif mode == "NN":
+            bt = bd.t().contiguous()
+            H.gemm(H.AC_GEMM_NN, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bt), N),
+                   H.mat(H._p(c3), N), math=1)
+        else:
+            at, bt = ad.t().contiguous(), bd.t().contiguous()
+            H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(at), M), H.mat(H._p(bt), N),
+                   H.mat(H._p(c3), N), math=1)
+        ref = a.bfloat16().float() @ b.bfloat16().float().t()
+        close(c3, ref, tol=1e-3, name=f"bf16 {mode}")
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "relu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("shape", [(3, 50, 96, 384), (1, 512, 288, 128), (1, 512, 2, 16), (1, 77, 19, 5)])
+def test_linear_autograd(dev, act, shape):
+    from applecider_amd import hipops as H
+    lead, rows, K, N = shape
+    x = g(dev, lead, rows, K, seed=1).requires_grad_()
+    w = (g(dev, N, K, seed=2) / math.sqrt(K)).requires_grad_()
+    b = g(dev, N, seed=3).requires_grad_()
+    fn = {None: lambda t: t, "gelu": F.gelu, "relu": F.relu, "sigmoid": torch.sigmoid,
+          "tanh": torch.tanh}[act]
+    y = fn(F.linear(x, w, b))
+    go = g(dev, *y.shape, seed=4)
+    y.backward(go)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+    yd = H.linear(xd, wd, bd, act=act)
+    yd.backward(go.to(dev))
+    close(yd, y, name="y")
+    close(xd.grad, x.grad, name="dx")
+    close(wd.grad, w.grad, name="dw")
+    close(bd.grad, b.grad, name="db")
+
+
+def test_linear_residual_colscale(dev):
+    from applecider_amd import hipops as H
+    x = g(dev, 450, 384, seed=1).requires_grad_()
+    w = (g(dev, 96, 384, seed=2) / 20).requires_grad_()
+    b = g(dev, 96, seed=3).requires_grad_()
+    gam = g(dev, 96, seed=4).requires_grad_()
+    res = g(dev, 450, 96, seed=5).requires_grad_()
+    y = res + gam * F.linear(x, w, b)
+    go = g(dev, 450, 96, seed=6)
+    y.backward(go)
+    ts = [t.detach().to(dev).requires_grad_() for t in (x, w, b, gam, res)]
+    yd = H.linear(ts[0], ts[1], ts[2], residual=ts[4], colscale=ts[3])
+    yd.backward(go.to(dev))
+    close(yd, y, name="y")
+    for td, t, n in zip(ts, (x, w, b, gam, res), "x w b gamma res".split()):
+        close(td.grad, t.grad, name="d" + n)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,C", [(1000, 96), (333, 192), (64, 3072), (512, 5), (100, 130)])
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_layernorm(dev, rows, C, act):
+    from applecider_amd import hipops as H
+    x = (g(dev, rows, C, seed=1) * 2 + 0.5).requires_grad_()
+    w = (1 + 0.1 * g(dev, C, seed=2)).requires_grad_()
+    b = (0.1 * g(dev, C, seed=3)).requires_grad_()
+    y = F.layer_norm(x, (C,), w, b, 1e-6)
+    if act:
+        y = F.gelu(y)
+    go = g(dev, rows, C, seed=4)
+    y.backward(go)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+    yd = H.layer_norm(xd, wd, bd, 1e-6, act=act)
+    yd.backward(go.to(dev))
+    close(yd, y, name="y")
+    close(xd.grad, x.grad, name="dx")
+    close(wd.grad, w.grad, name="dgamma")
+    close(bd.grad, b.grad, name="dbeta")
+
+
+# ----------------------------------------------------------------------------- image branch
+@pytest.mark.parametrize("B,H_,C", [(5, 15, 96), (3, 7, 192), (6, 3, 384), (9, 1, 768), (2, 15, 40)])
+def test_dwconv(dev, B, H_, C):
+    from applecider_amd import hipops as H
+    x = g(dev, B, C, H_, H_, seed=1).requires_grad_()
+    w = (g(dev, C, 1, 7, 7, seed=2) / 7).requires_grad_()
+    b = g(dev, C, seed=3).requires_grad_()
+    y = F.conv2d(x, w, b, padding=3, groups=C)
+    go = g(dev, *y.shape, seed=4)
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_()
+    wd = w.detach().reshape(C, 49).t().contiguous().to(dev).requires_grad_()
+    bd = b.detach().to(dev).requires_grad_()
+    yd = H.dwconv7x7(xd, wd, bd)
+    yd.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(yd.permute(0, 3, 1, 2), y, name="y")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, name="dx")
+    close(wd.grad.t().reshape(C, 1, 7, 7), w.grad, name="dw")
+    close(bd.grad, b.grad, name="db")
+
+
+@pytest.mark.parametrize("B,H_,C,Co", [(4, 15, 96, 192), (4, 7, 192, 384), (8, 3, 384, 768), (3, 8, 32, 64)])
+def test_patch_conv2x2(dev, B, H_, C, Co):
+    from applecider_amd import hipops as H
+    x = g(dev, B, C, H_, H_, seed=1).requires_grad_()
+    w = (g(dev, Co, C, 2, 2, seed=2) / math.sqrt(4 * C)).requires_grad_()
+    b = g(dev, Co, seed=3).requires_grad_()
+    y = F.conv2d(x, w, b, stride=2)
+    go = g(dev, *y.shape, seed=4)
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_()
+    wd = w.detach().permute(0, 2, 3, 1).reshape(Co, 4 * C).contiguous().to(dev).requires_grad_()
+    bd = b.detach().to(dev).requires_grad_()
+    yd = H.patch_conv2x2(xd, wd, bd)
+    yd.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(yd.permute(0, 3, 1, 2), y, name="y")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, name="dx")
+    close(wd.grad.reshape(Co, 2, 2, C).permute(0, 3, 1, 2), w.grad, name="dw")
+    close(bd.grad, b.grad, name="db")
+
+
+def test_stem(dev):
+    from applecider_amd import hipops as H
+    B = 6
+    img = g(dev, B, 3, 63, 63, seed=1)
+    w = (g(dev, 96, 3, 4, 4, seed=2) / 7).requires_grad_()
+    b = g(dev, 96, seed=3).requires_grad_()
+    y = F.conv2d(img, w, b, stride=4)  # [B,96,15,15]
+    go = g(dev, *y.shape, seed=4)
+    y.backward(go)
+    w64 = torch.zeros(96, 64)
+    w64[:, :48] = w.detach().permute(0, 2, 3, 1).reshape(96, 48)
+    wd = w64.to(dev).requires_grad_()
+    bd = b.detach().to(dev).requires_grad_()
+    patches, OH, OW = H.stem_patchify(img.to(dev))
+    assert (OH, OW) == (15, 15)
+    yd = H.linear(patches, wd, bd)
+    yd.backward(go.permute(0, 2, 3, 1).reshape(-1, 96).contiguous().to(dev))
+    close(yd.reshape(B, 15, 15, 96).permute(0, 3, 1, 2), y, name="y")
+    close(wd.grad[:, :48].reshape(96, 4, 4, 3).permute(0, 3, 1, 2), w.grad, name="dw")
+    assert wd.grad[:, 48:].abs().max().item() == 0.0
+    close(bd.grad, b.grad, name="db")
+
+
+def test_pools(dev):
+    from applecider_amd import hipops as H
+    x = g(dev, 3, 64, 40, seed=1).requires_grad_()  # [B, L, C]
+    y = F.max_pool1d(x.permute(0, 2, 1), 4).permute(0, 2, 1)
+    go = g(dev, *y.shape, seed=2)
+    y.backward(go)
+    xd = x.detach().to(dev).requires_grad_()
+    yd = H.maxpool4(xd)
+    yd.backward(go.to(dev))
+    close(yd, y, tol=0, name="maxpool")
+    close(xd.grad, x.grad, tol=0, name="maxpool dx")
+    x.grad = None
+    y = F.adaptive_max_pool1d(x.permute(0, 2, 1), 1).squeeze(-1)
+    go = g(dev, *y.shape, seed=3)
+    y.backward(go)
+    xd = x.detach().to(dev).requires_grad_()
+    yd = H.global_max(xd)
+    yd.backward(go.to(dev))
+    close(yd, y, tol=0, name="globalmax")
+    close(xd.grad, x.grad, tol=0, name="globalmax dx")
+    x.grad = None
+    y = x.mean(1)
+    y.backward(go)
+    xd = x.detach().to(dev).requires_grad_()
+    yd = H.avgpool_tokens(xd)
+    yd.backward(go.to(dev))
+    close(yd, y, name="avgpool")
+    close(xd.grad, x.grad, name="avgpool dx")
+
+
+# ----------------------------------------------------------------------------- spectra conv bank
+@pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 1, 64, (3, 61, 1021)), (3, 64, 1, 32, (3, 7, 13)),
+                                             (2, 128, 64, 128, (3, 31, 251)), (2, 16, 32, 64, (3, 7, 13)),
+                                             (1, 64, 128, 32, (3, 15, 61))])
+def test_conv_group1d(dev, B, L, Cin, Cout, ks):
+    from applecider_amd import hipops as H
+    x = g(dev, B, Cin, L, seed=1).requires_grad_(Cin != 1)
+    ws = [(g(dev, Cout, Cin, k, seed=10 + i) / math.sqrt(Cin * k)).requires_grad_() for i, k in enumerate(ks)]
+    bs = [g(dev, Cout, seed=20 + i).requires_grad_() for i in range(len(ks))]
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)  # [B, 3Cout, L]
+    go = g(dev, *y.shape, seed=5)
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 1).contiguous().to(dev).requires_grad_(Cin != 1)
+    wd = [w.detach().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+    bd = [b.detach().to(dev).requires_grad_() for b in bs]
+    yd = H.conv_group1d(xd, ks, wd, bd)
+    yd.backward(go.permute(0, 2, 1).contiguous().to(dev))
+    close(yd.permute(0, 2, 1), y, name="y")
+    for i, k in enumerate(ks):
+        close(wd[i].grad.reshape(Cout, k, Cin).permute(0, 2, 1), ws[i].grad, name=f"dw{i}")
+        close(bd[i].grad, bs[i].grad, name=f"db{i}")
+    if Cin != 1:
+        close(xd.grad.permute(0, 2, 1), x.grad, name="dx")
+
+
+# ----------------------------------------------------------------------------- photometry branch
+def test_embed(dev):
+    from applecider_amd import hipops as H
+    B, L, D = 3, 20, 128
+    x = g(dev, B, L, 7, seed=1)
+    W = (g(dev, D, 7, seed=2) / 3).requires_grad_()
+    bias = g(dev, D, seed=3).requires_grad_()
+    w0, b0 = g(dev, 1, seed=4).requires_grad_(), g(dev, 1, seed=5).requires_grad_()
+    w, b = g(dev, D - 1, seed=6).requires_grad_(), g(dev, D - 1, seed=7).requires_grad_()
+    cls = g(dev, 1, 1, D, seed=8).requires_grad_()
+    t = x[..., 0]
+    te = torch.cat([(w0 * t + b0).unsqueeze(-1), torch.sin(t.unsqueeze(-1) * w + b)], -1)
+    h = torch.cat([cls.expand(B, -1, -1), F.linear(x, W, bias) + te], 1)
+    go = g(dev, *h.shape, seed=9)
+    h.backward(go)
+    x8 = H.pad_channels(x.to(dev), 8)
+    W8 = torch.zeros(D, 8)
+    W8[:, :7] = W.detach()
+    W8d = W8.to(dev).requires_grad_()
+    biasd = bias.detach().to(dev).requires_grad_()
+    twd = torch.cat([w0.detach(), w.detach()]).to(dev).requires_grad_()
+    tbd = torch.cat([b0.detach(), b.detach()]).to(dev).requires_grad_()
+    clsd = cls.detach().reshape(D).to(dev).requires_grad_()
+    hd = H.embed(x8, W8d, biasd, twd, tbd, clsd)
+    hd.backward(go.to(dev))
+    close(hd, h, name="h")
+    close(W8d.grad[:, :7], W.grad, name="dW")
+    close(biasd.grad, bias.grad, name="dbias")
+    close(twd.grad, torch.cat([w0.grad, w.grad]), name="dtw")
+    close(tbd.grad, torch.cat([b0.grad, b.grad]), name="dtb")
+    close(clsd.grad, cls.grad.reshape(D), name="dcls")
+
+
+@pytest.mark.parametrize("B,T,H_", [(3, 129, 8), (2, 258, 8), (4, 20, 4)])
+def test_mha(dev, B, T, H_):
+    from applecider_amd import hipops as H
+    Dh = 16
+    D = H_ * Dh
+    qkv = g(dev, B, T, 3 * D, seed=1).requires_grad_()
+    lens = [T, max(2, T // 3), 1, 7][:B]
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        pad[i, n:] = True
+    q, k, v = qkv.split(D, -1)
+    sh = lambda t: t.reshape(B, T, H_, Dh).permute(0, 2, 1, 3)
+    s = (sh(q) / math.sqrt(Dh)) @ sh(k).transpose(-1, -2)
+    s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    o = (torch.softmax(s, -1) @ sh(v)).permute(0, 2, 1, 3).reshape(B, T, D)
+    go = g(dev, B, T, D, seed=2)
+    o.backward(go)
+    qd = qkv.detach().to(dev).requires_grad_()
+    od = H.mha(qd, pad.to(torch.uint8).to(dev), H_)
+    od.backward(go.to(dev))
+    close(od, o, name="out")
+    close(qd.grad, qkv.grad, name="dqkv")
+
+
+def test_mha_dropout_consistency(dev):
+    """Dropout inside attention: forward/backward must use the same mask -> check the gradient of
+    a linear functional by finite differences along a random direction."""
+    from applecider_amd import hipops as H
+    B, T, H_, D = 2, 33, 8, 128
+    qkv = g(dev, B, T, 3 * D, seed=1).to(dev)
+    go = g(dev, B, T, D, seed=2).to(dev)
+    dirn = g(dev, B, T, 3 * D, seed=3).to(dev)
+    pad = torch.zeros(B, T, dtype=torch.uint8, device=dev)
+    seed = 1234567
+    f = lambda t: (H._MHA.apply(t, pad, H_, 0.4, seed) * go).sum()
+    q = qkv.clone().requires_grad_()
+    f(q).backward()
+    analytic = (q.grad * dirn).sum().item()
+    e = 1e-2
+    numeric = (f(qkv + e * dirn).item() - f(qkv - e * dirn).item()) / (2 * e)
+    assert abs(analytic - numeric) <= 2e-2 * max(1.0, abs(numeric)), (analytic, numeric)
+    # keep-rate statistics through V = ones: each output is sum_j keep_ij P_ij / (1-p), mean 1
+    qkv1 = qkv.clone()
+    qkv1[..., 2 * D:] = 1.0
+    o = H._MHA.apply(qkv1, pad, H_, 0.4, seed)
+    assert abs(o.mean().item() - 1.0) < 0.02
+
+
+# ----------------------------------------------------------------------------- small ops
+def test_small_ops(dev):
+    from applecider_amd import hipops as H
+    a, b_, s = (g(dev, 100, 32, seed=i).requires_grad_() for i in (1, 2, 3))
+    y = a * b_ + s
+    go = g(dev, 100, 32, seed=4)
+    y.backward(go)
+    ad, bd, sd = (t.detach().to(dev).requires_grad_() for t in (a, b_, s))
+    yd = H.gate(ad, bd, sd)
+    yd.backward(go.to(dev))
+    close(yd, y, name="gate")
+    close(ad.grad, a.grad), close(bd.grad, b_.grad), close(sd.grad, s.grad)
+    # cat / gather / l2norm / add / act / take_token
+    md = g(dev, 50, 24, seed=5)
+    idx = [6, 9, 10, 13, 15, 17, 18]
+    close(H.gather_cols(md.to(dev), torch.tensor(idx, dtype=torch.int32, device=dev)), md[:, idx], tol=0)
+    parts = [g(dev, 50, n, seed=10 + n).requires_grad_() for n in (32, 5, 32)]
+    yc = torch.cat(parts, 1)
+    goc = g(dev, *yc.shape, seed=6)
+    yc.backward(goc)
+    pd_ = [p.detach().to(dev).requires_grad_() for p in parts]
+    ycd = H.cat_cols(pd_)
+    ycd.backward(goc.to(dev))
+    close(ycd, yc, tol=0)
+    for p, q in zip(pd_, parts):
+        close(p.grad, q.grad, tol=0)
+    x = g(dev, 64, 64, seed=7).requires_grad_()
+    yn = x / x.norm(dim=-1, keepdim=True)
+    gon = g(dev, 64, 64, seed=8)
+    yn.backward(gon)
+    xd = x.detach().to(dev).requires_grad_()
+    ynd = H.l2_normalize(xd)
+    ynd.backward(gon.to(dev))
+    close(ynd, yn), close(xd.grad, x.grad, name="l2 dx")
+    for kind, fn in (("gelu", F.gelu), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid), ("relu", F.relu)):
+        x.grad = None
+        ya = fn(x)
+        ya.backward(gon)
+        xd = x.detach().to(dev).requires_grad_()
+        yad = H.activation(xd, kind)
+        yad.backward(gon.to(dev))
+        close(yad, ya, name=kind), close(xd.grad, x.grad, name="d" + kind)
+    z = g(dev, 4, 9, 16, seed=9).requires_grad_()
+    z[:, 0].backward(g(dev, 4, 16, seed=10))
+    zd = z.detach().to(dev).requires_grad_()
+    td = H.take_token(zd, 0)
+    td.backward(g(dev, 4, 16, seed=10).to(dev))
+    close(td, z[:, 0], tol=0), close(zd.grad, z.grad, tol=0)
+    close(H.add(ad.detach(), bd.detach(), 1 / 3), (a + b_) / 3)
+    close(H.softmax_rows(md.to(dev)), torch.softmax(md, -1))
+
+
+def test_moe_top2(dev):
+    from applecider_amd import hipops as H
+    B, E, Cn = 200, 4, 5
+    sc = torch.sigmoid(g(dev, B, E, seed=1)).requires_grad_()
+    eo = g(dev, E, B, Cn, seed=2).requires_grad_()
+    tw, ti = torch.topk(sc, k=2, dim=-1)
+    out = torch.zeros(B, Cn)
+    for e in range(E):
+        mask = (ti == e).any(-1)
+        if mask.any():
+            wts = tw[mask, (ti[mask] == e).nonzero()[:, 1]]
+            out[mask] = out[mask] + wts.unsqueeze(-1) * eo[e][mask]
+    go = g(dev, B, Cn, seed=3)
+    out.backward(go)
+    scd, eod = sc.detach().to(dev).requires_grad_(), eo.detach().to(dev).requires_grad_()
+    outd, sel = H.moe_top2(scd, eod)
+    outd.backward(go.to(dev))
+    close(outd, out, tol=1e-6)
+    assert torch.equal(sel.cpu().long(), ti)
+    close(scd.grad, sc.grad, tol=1e-6), close(eod.grad, eo.grad, tol=1e-6)
+
+
+def test_losses(dev):
+    from applecider_amd import hipops as H
+    B, Cn = 300, 5
+    z = (g(dev, B, Cn, seed=1) * 2).requires_grad_()
+    t = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(2))
+    onehot = F.one_hot(t, Cn).float()
+
+    def focal(logits, target, gamma, alpha, eps):
+        logp = F.log_softmax(logits, 1)
+        p = logp.exp()
+        if eps > 0:
+            y = torch.full_like(logp, eps / (Cn - 1))
+            y.scatter_(1, target.unsqueeze(1), 1 - eps)
+        else:
+            y = F.one_hot(target, Cn).float()
+        fw = (1 - p).pow(gamma)
+        if alpha is not None:
+            fw = fw * alpha.view(1, Cn)
+        return -(y * fw * logp).sum(1).mean()
+
+    alpha = torch.tensor([0.3, 0.1, 0.1, 0.3, 0.2])
+    cases = [("soft", lambda zz: F.cross_entropy(zz, onehot), lambda zd: H.cross_entropy_soft(zd, onehot.to(dev))),
+             ("index", lambda zz: F.cross_entropy(zz, t), lambda zd: H.cross_entropy_index(zd, t.to(dev)))]
+    for gamma in (0.0, 2.0, 1.5):
+        for al in (None, alpha):
+            for eps in (0.0, 0.1):
+                cases.append((f"focal g{gamma} a{al is not None} e{eps}",
+                              lambda zz, gamma=gamma, al=al, eps=eps: focal(zz, t, gamma, al, eps),
+                              lambda zd, gamma=gamma, al=al, eps=eps: H.focal_loss(
+                                  zd, t.to(dev), gamma, al.to(dev) if al is not None else None, eps)))
+    for name, ref_fn, hip_fn in cases:
+        z.grad = None
+        l = ref_fn(z)
+        l.backward()
+        zd = z.detach().to(dev).requires_grad_()
+        ld = hip_fn(zd)
+        ld.backward()
+        assert abs(ld.item() - l.item()) <= 1e-5 * max(1, abs(l.item())), name
+        close(zd.grad, z.grad, tol=1e-4, name=name)
+
+
+def test_dropout_stats(dev):
+    from applecider_amd import hipops as H
+    x = torch.ones(1 << 20, device=dev, requires_grad=True)
+    for p in (0.25, 0.4, 0.5):
+        y = H.dropout(x, p, True)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 5e-3
+        assert abs(y.mean().item() - 1.0) < 1e-2
+        x.grad = None
+        y.sum().backward()
+        assert torch.equal(x.grad, y.detach())  # same mask, same scale
+    y1, y2 = H.dropout(x, 0.5, True), H.dropout(x, 0.5, True)
+    assert not torch.equal(y1, y2)  # fresh seed per call
+    assert H.dropout(x, 0.5, False) is x
+
+
+def test_optimizers(dev):
+    from applecider_amd import hipops as H
+    from applecider_amd._lib import AdamSeg
+    n = 10000
+    p0, g0 = g(dev, n, seed=1), g(dev, n, seed=2)
+    for decoupled, Opt in ((1, torch.optim.AdamW), (0, torch.optim.Adam)):
+        p = p0.clone().requires_grad_()
+        opt = Opt([{"params": [p], "lr": 3e-3, "weight_decay": 0.05, "betas": (0.9, 0.99)}], eps=5e-10)
+        pd_, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        for step in range(1, 4):
+            gr = g0 * step
+            p.grad = gr.clone()
+            opt.step()
+            H.adam_flat(pd_, gr.to(dev), m, v, [AdamSeg(0, n // 2, 3e-3, 0.9, 0.99, 5e-10, 0.05, decoupled),
+                                                AdamSeg(n // 2, n, 3e-3, 0.9, 0.99, 5e-10, 0.05, decoupled)], step)
+        close(pd_, p, tol=1e-5, name=f"adam decoupled={decoupled}")
+    p = p0.clone().requires_grad_()
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9)
+    pd_, buf = p0.clone().to(dev), torch.zeros(n, device=dev)
+    for step in range(3):
+        p.grad = g0.clone()
+        opt.step()
+        H.sgd_flat(pd_, g0.to(dev), buf, 0.01, 0.9, 0.0, step == 0)
+    close(pd_, p, tol=1e-6, name="sgd")
+    gd = (g0 * 3).to(dev)
+    coef, ss = H.clip_coef(gd, 1.0)
+    tot = (g0 * 3).norm().item()
+    assert abs(math.sqrt(ss.item()) - tot) < 1e-3 * tot
+    assert abs(coef.item() - min(1.0, 1.0 / (tot + 1e-6))) < 1e-6
