@@ -1,0 +1,107 @@
+"""Host-side collation of AppleCiDEr sample dicts and the pinned-host async H2D staging
+(SURVEY.md §8f-1).
+
+`collate_photometry` mirrors PhotoEventsDataset.collate (src/applecider/datasets/photo_dataset.py:
+117-152): pad to max(257, longest) with zeros, build the True=padding mask, truncate to 257.
+`collate_fused` mirrors the 5-modal legacy collate (src/applecider/models/Time2Vec.py:18-45) — tuple
+order (photometry, photo_mask, metadata, images, spectra, labels) — but takes mean/std as arguments
+(the reference hard-codes a path) and leaves device placement to `PinnedStager`, which replaces the
+blocking `.to(device)` calls (brew_cider.py:991-994) with double-buffered pinned staging and
+non-blocking copies on a dedicated copy stream.
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+
+MAX_LEN = 257  # default_config.toml:64
+
+
+def collate_photometry(batch: Sequence[dict]) -> dict:
+    seqs, labels = [], []
+    for item in batch:
+        seqs.append(np.asarray(item["data"]["photometry"]))
+        if "label" in item["data"]:
+            labels.append(item["data"]["label"])
+    lengths = [s.shape[0] for s in seqs]
+    width = max(MAX_LEN, max(lengths))
+    out = np.zeros((len(seqs), width, seqs[0].shape[1]), dtype=seqs[0].dtype)
+    pad_mask = np.ones((len(seqs), width), dtype=bool)
+    for i, s in enumerate(seqs):
+        out[i, :s.shape[0]] = s
+        pad_mask[i, :s.shape[0]] = False
+    return {"data": {"photometry": out[:, :MAX_LEN, :], "label": np.array(labels),
+                     "pad_mask": pad_mask[:, :MAX_LEN],
+                     "mean": np.array(batch[0]["data"]["mean"]),
+                     "std": np.array(batch[0]["data"]["std"])}}
+
+
+def collate_fused(batch: Sequence[tuple], mean: np.ndarray, std: np.ndarray, max_len: int = None):
+    """batch of (photo_seq [l,7], metadata [24], image [3,63,63], spectrum [1,S], label) ->
+    host tuple (photometry f32[B,L,7] normalised, photo_mask bool[B,L], metadata, images, spectra,
+    labels i64)."""
+    photo, metadata, images, spectra, labels = zip(*batch)
+    lens = [np.asarray(s).shape[0] for s in photo]
+    L = max_len or max(lens)
+    B = len(batch)
+    ph = np.zeros((B, L, 7), dtype=np.float32)
+    mask = np.ones((B, L), dtype=bool)
+    for i, s in enumerate(photo):
+        n = min(lens[i], L)
+        ph[i, :n] = np.asarray(s, dtype=np.float32)[:n]
+        mask[i, :n] = False
+    ph[..., :4] = (ph[..., :4] - np.asarray(mean, np.float32)) / (np.asarray(std, np.float32) + 1e-8)
+    return (ph, mask, np.stack([np.asarray(m, np.float32) for m in metadata]),
+            np.stack([np.asarray(im, np.float32) for im in images]),
+            np.stack([np.asarray(sp, np.float32) for sp in spectra]),
+            np.asarray(labels, dtype=np.int64))
+
+
+class PinnedStager:
+    """Double-buffered pinned-host staging + async H2D on a copy stream.
+
+        stager = PinnedStager(device)
+        dev_batch = stager.stage(host_tuple)    # returns device tensors; copy overlaps compute
+
+    The returned tensors are safe to use on the current stream: the stage records an event on the
+    copy stream and the current stream waits on it (no host synchronisation).
+    """
+
+    def __init__(self, device, depth: int = 2):
+        self.device = torch.device(device)
+        self.depth = depth
+        self.slot = 0
+        self.host = [dict() for _ in range(depth)]
+        self.events = [None] * depth
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def _pinned(self, slot, key, arr: np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        buf = self.host[slot].get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=self.device.type == "cuda")
+            self.host[slot][key] = buf
+        buf.copy_(t)
+        return buf
+
+    def stage(self, host_tuple):
+        slot = self.slot
+        self.slot = (self.slot + 1) % self.depth
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()  # pinned buffer of this slot is free again
+        if self.copy_stream is None:
+            return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in host_tuple)
+        outs = []
+        with torch.cuda.stream(self.copy_stream):
+            for i, a in enumerate(host_tuple):
+                outs.append(self._pinned(slot, i, a).to(self.device, non_blocking=True))
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.events[slot] = ev
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        for o in outs:
+            o.record_stream(torch.cuda.current_stream(self.device))
+        return tuple(outs)

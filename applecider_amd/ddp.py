@@ -1,0 +1,127 @@
+"""Data-parallel gradient exchange for the MI355X path.
+
+The reference has no multi-process code at all; the path shards purely by batch (samples are
+independent: LayerNorm/softmax are per-sample, there is no BatchNorm on the default path), so the only
+exchange per step is a gradient all-reduce.  One process per GPU, `torch.distributed` backend "nccl"
+(= RCCL over xGMI on ROCm); "gloo" on CPU for tests.
+
+Design for MI355X: gradients already live in ONE contiguous fp32 buffer (applecider_amd.optim), so a
+bucket is just a slice of it — no packing copies, few large collectives (xGMI rings are per-link
+bound, so bigger messages amortise the ~10 us launch/latency floor).  Buckets are cut at parameter
+boundaries in buffer order; a bucket is launched from autograd's post-accumulate hooks as soon as
+every parameter in it has its gradient, i.e. while the rest of backward is still running (RCCL runs
+on its own stream and only waits for the work queued so far).  `finish()` launches whatever is left
+(parameters that received no gradient), waits, and averages on the device.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, flat_params, process_group=None, bucket_bytes: int = 32 << 20,
+                 overlap: bool = True):
+        """flat_params: applecider_amd.optim.FlatParameters (already flattened)."""
+        self.fp = flat_params
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.buckets: List[tuple] = []      # (begin, end) element ranges of the flat grad buffer
+        self.bucket_of: List[int] = []      # parameter index -> bucket index
+        self.pending: List[int] = []
+        self.counts: List[int] = []
+        self.handles: list = []
+        self.launched: List[bool] = []
+        self._hooks = []
+        self._build(bucket_bytes // 4)
+        self._inv_world = None
+        if self.world > 1:
+            for i, p in enumerate(self.fp.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _build(self, bucket_elems: int):
+        begin, n, cur = 0, 0, 0
+        sizes = [self.fp._round(p.numel()) for p in self.fp.params]
+        count = 0
+        for i, (off, sz) in enumerate(zip(self.fp.offsets, sizes)):
+            self.bucket_of.append(cur)
+            n += sz
+            count += 1
+            if n >= bucket_elems or i == len(sizes) - 1:
+                self.buckets.append((begin, off + sz))
+                self.counts.append(count)
+                begin, n, count = off + sz, 0, 0
+                cur += 1
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.counts)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def _launch(self, b: int):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        lo, hi = self.buckets[b]
+        view = self.fp.grad[lo:hi]
+        self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
+                                            async_op=True))
+
+    def _make_hook(self, idx: int):
+        def hook(_param):
+            b = self.bucket_of[idx]
+            self.pending[b] -= 1
+            if self.pending[b] == 0 and self.overlap:
+                self._launch(b)
+        return hook
+
+    def finish(self):
+        """Call after backward(): completes the exchange and leaves the AVERAGED gradient in the
+        flat buffer.  No host synchronisation on GPU (stream waits only)."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for h in self.handles:
+            h.wait()
+        g = self.fp.grad
+        if g.is_cuda:
+            from . import hipops as H
+            if self._inv_world is None or self._inv_world.device != g.device:
+                self._inv_world = torch.full((1,), 1.0 / self.world, device=g.device)
+            H._lib.check(H._lib_().ac_scale_by_dev(H._p(g), g.numel(), H._p(self._inv_world),
+                                                   H._stream()), "ac_scale_by_dev")
+        else:
+            g.mul_(1.0 / self.world)  # gloo / CPU test path
+        self.reset()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def init_from_env(backend: Optional[str] = None):
+    """One process per GPU, rendezvous from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_parameters(flat_params, src: int = 0, process_group=None):
+    """All ranks start from rank `src`'s weights (one collective over the flat buffer)."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat_params.flat, src=src, group=process_group)

@@ -1,0 +1,125 @@
+"""SpectraNet (multi-scale 1-D CNN over 4096-bin spectra) on the MI355X path.
+
+Drop-in for src/applecider/models/spectranet.py: `SpectraNetBlock(in_channels, out_channels,
+kernel_sizes, use_ln, do_pool)`, `make_stage(...)`, `SpectraNet(config, data_sample)`,
+`forward((flux, labels, redshifts))`, `train_step`, `to_tensor`; same state_dict keys/shapes
+(`all_stages.{i}.{j}.convs.{n}.weight` [Cout, Cin, k], ...).
+
+This branch is 92 % of the model's FLOPs.  Sequences are channels-last
+[B, L, C]; each block is
+  conv bank   3 parallel 'same' Conv1d as implicit GEMMs on the matrix cores, written straight into
+              the channel-concatenated buffer (no torch.cat); stage 1 (Cin = 1, k up to 1021) uses
+              the 8-phase Toeplitz form (hipops._ConvGroup1d)
+  LN + GELU   one row kernel over the 3*Cout channels of each position
+  1x1 conv    plain GEMM, then MaxPool1d(4) as a streaming kernel
+BatchNorm stages (use_ln=False) are not on the default path (default_config.toml:105) and raise.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+from ..hyrax_compat import hyrax_model
+from ._layers import Conv1dTap, Dropout, LayerNorm, Linear, Marker, PointConv1d
+
+
+class SpectraNetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_sizes, use_ln=True, do_pool=False):
+        super().__init__()
+        if not use_ln:
+            raise NotImplementedError("BatchNorm stages are not on the MI355X path (use_ln=True only)")
+        self.do_pool, self.use_ln = do_pool, use_ln
+        self.k = len(kernel_sizes)
+        self.kernel_sizes = tuple(int(k) for k in kernel_sizes)
+        norm_channels = out_channels * self.k
+        self.convs = nn.ModuleList([Conv1dTap(in_channels, out_channels, k) for k in self.kernel_sizes])
+        self.norm = LayerNorm(norm_channels)
+        if do_pool:
+            self.total_pooled_channels = norm_channels
+            self.downsample = PointConv1d(norm_channels, out_channels)
+
+    def forward(self, x):  # x: [B, L, Cin] channels-last
+        y = H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs],
+                           [c.bias for c in self.convs])
+        y = self.norm(y, act="gelu")
+        if self.do_pool:
+            y = H.maxpool4(self.downsample(y))
+        return y
+
+
+def make_stage(in_channel, out_channel, depth, kernel_sizes, use_ln=True, do_pool=True):
+    """One SpectraNet stage: `depth` blocks, pooling on the last (spectranet.py:44-82).
+    Returns (nn.Sequential, number of kernels)."""
+    k = len(kernel_sizes)
+    blocks = [SpectraNetBlock(in_channels=in_channel if i == 0 else out_channel * k,
+                              out_channels=out_channel, kernel_sizes=kernel_sizes, use_ln=use_ln,
+                              do_pool=(do_pool if i == depth - 1 else False))
+              for i in range(depth)]
+    return nn.Sequential(*blocks), k
+
+
+@hyrax_model
+class SpectraNet(nn.Module):
+    def __init__(self, config=None, data_sample=None):
+        super().__init__()
+        self.config = config
+        sc = config["model"]["SpectraNet"]
+        self.redshift = sc["redshift"]
+        kernel_sizes_per_stage = sc["kernel_sizes_per_stage"]
+        depths, use_ln_stages, channels = sc["depths"], sc["use_ln_stages"], sc["channels"]
+        flat_dim, class_order = sc["flat_dim"], sc["class_order"]
+        # the reference's chained `!=` (spectranet.py:108) only compares neighbours; check all
+        if not (len(depths) == len(use_ln_stages) == len(channels) == len(kernel_sizes_per_stage)):
+            raise ValueError(
+                "depths, use_ln_stages, channels, and kernel_sizes_per_stage must be the same length.")
+        self.stages, self.ks = [], []
+        for i in range(len(depths)):
+            stage, k = make_stage(in_channel=1 if i == 0 else channels[i - 1], out_channel=channels[i],
+                                  depth=depths[i], kernel_sizes=kernel_sizes_per_stage[i],
+                                  use_ln=use_ln_stages[i], do_pool=i != len(depths) - 1)
+            self.stages.append(stage)
+            self.ks.append(k)
+        self.all_stages = nn.Sequential(*self.stages)
+        head = nn.Sequential(Linear(flat_dim, 384), LayerNorm(384), Marker("gelu"), Dropout(0.5),
+                             Linear(384, 1 if self.redshift else class_order))
+        if self.redshift:
+            self.regressor = head
+        else:
+            self.classifier = head
+
+    def forward(self, batch):
+        x, _, _ = batch  # flux [B, 1, L]
+        B, Cin, L = x.shape
+        if Cin != 1:
+            raise ValueError("SpectraNet expects flux of shape [B, 1, L]")
+        h = self.all_stages(x.reshape(B, L, 1))  # [B,1,L] and [B,L,1] share memory for Cin = 1
+        z = H.global_max(h)  # adaptive_max_pool1d(., 1): [B, C]
+        head = self.regressor if self.redshift else self.classifier
+        z = head[3](head[1](head[0](z), act="gelu"))
+        out = head[4](z)
+        return out.squeeze(1) if self.redshift else out
+
+    def train_step(self, batch):
+        """Uses self.optimizer / self.criterion injected by Hyrax (spectranet.py:172-184); with no
+        injection, `applecider_amd.training.attach_defaults(model)` sets SGD(0.01, 0.9) + CE."""
+        _, labels, redshifts = batch
+        self.optimizer.zero_grad()
+        outputs = self(batch)
+        loss = self.criterion(outputs, redshifts if self.redshift else labels)
+        loss.backward()
+        self.optimizer.step()
+        return {"loss": loss.item()}
+
+    @staticmethod
+    def to_tensor(data_dict):
+        """Sample dict -> (flux f32, label i16, redshift f32); numpy only (spectranet.py:186-206)."""
+        import numpy as np
+
+        if "data" not in data_dict:
+            raise ValueError("Data dictionary must have a 'data' key.")
+        data = data_dict["data"]
+        return (np.asarray(data.get("flux", []), dtype=np.float32),
+                np.asarray(data.get("label", []), dtype=np.int16),
+                np.asarray(data.get("redshift", []), dtype=np.float32))

