@@ -1,0 +1,218 @@
+"""bench.py — headline benchmark of the MI355X path.
+
+    python bench.py --gpus N --steps K --warmup W [--math bf16|f32] [--batch 512]
+
+Workload (BASELINE.json configs[2], the configuration the metric "multimodal samples/sec/GPU
+(fwd+bwd) at batch 512" is quoted on): the full 4-modality AppleCiDEr model — image 63x63x3 +
+metadata 24 + photometry 128x7 + spectra 4096 — one training step = zero_grad, forward, CrossEntropy,
+backward, (gradient all-reduce when N > 1), Adam step, dropout active as in the reference's training,
+on a synthetic batch of 512 samples per GPU already resident in HBM.  N > 1: one process per GPU
+(torch.distributed.run), batch rows sharded by rank (weak scaling), RCCL all-reduce of the flat
+gradient buffer overlapped with backward.
+
+Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
+  roofline     dominant kernel (the gather-GEMM family that carries the Conv1d implicit GEMMs):
+               algorithmic FLOP / launch duration from HIP events recorded around every launch inside
+               the timed region, against the dense MFMA peak of the math dtype.
+  cpu_baseline the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
+               bounded sample of the same workload (rank 0, N = 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+FUSION_CFG = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.4,
+              "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3,
+              "beta1": 0.9, "beta2": 0.999, "weight_decay": 0.01}  # brew_cider.py:195-215
+
+
+class KernelTimer:
+    """HIP-event brackets around every launch of selected entry points (on the launch stream)."""
+
+    def __init__(self):
+        self.records = {}  # name -> list of (start_event, end_event, work)
+        self.enabled = False
+
+    def wrap_gemm(self, H):
+        orig = H.gemm
+        names = {0: "gemm<NT>", 1: "gemm<NN>", 2: "gemm<TN>"}
+
+        def timed(mode, M, N, K, a, b, c, **kw):
+            if not self.enabled:
+                return orig(mode, M, N, K, a, b, c, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(mode, M, N, K, a, b, c, **kw)
+            e.record()
+            big = float(M) * N * K >= 262144.0  # the MFMA path (scalar kernel below that)
+            if big:
+                self.records.setdefault(names[mode], []).append((s, e, 2.0 * M * N * K))
+        H.gemm = timed
+
+    def wrap_dwconv(self, H):
+        lib = H._lib_()
+        orig = lib.ac_dwconv7x7_fwd
+
+        def timed(x, w, b, y, B, Hh, Ww, C, stream):
+            if not self.enabled:
+                return orig(x, w, b, y, B, Hh, Ww, C, stream)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig(x, w, b, y, B, Hh, Ww, C, stream)
+            e.record()
+            # algorithmic bytes: read x once, write y once (fp32 storage)
+            self.records.setdefault("dwconv7x7_fwd", []).append((s, e, 2.0 * B * Hh * Ww * C * 4))
+            return rc
+        lib.ac_dwconv7x7_fwd = timed
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            work = sum(w for _, _, w in recs)
+            out[name] = {"launches": len(recs), "ms": ms, "work": work}
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    from applecider_amd import ddp, hipops as H
+    from applecider_amd.config import default_config
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    H.set_math(args.math)
+
+    torch.manual_seed(1234)
+    model = AppleCider(dict(FUSION_CFG)).to(dev).train()
+    opt = model.optimizer.prepare()
+    gb = None
+    if world > 1:
+        ddp.broadcast_parameters(opt.fp)
+        gb = ddp.GradBuckets(opt.fp, overlap=not args.no_overlap)
+
+    B = args.batch
+    b = make_batch(B, seed=2 + 1000 * rank)
+    batch = tuple(torch.from_numpy(b[k]).to(dev) for k in
+                  ("photometry", "pad_mask", "metadata", "image", "spectra", "label"))
+
+    def step():
+        opt.zero_grad()
+        logits = model(*batch[:5])
+        loss = H.cross_entropy_index(logits, batch[5])
+        loss.backward()
+        if gb is not None:
+            gb.finish()
+        opt.step()
+        return loss
+
+    timer = KernelTimer()
+    timer.wrap_gemm(H)
+    timer.wrap_dwconv(H)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ks = timer.summary()
+    gemms = {k: v for k, v in ks.items() if k.startswith("gemm")}
+    dom_name = max(gemms, key=lambda k: gemms[k]["ms"])
+    dom = gemms[dom_name]
+    achieved = dom["work"] / (dom["ms"] * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.math]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": f"{dom_name} ({'gemm_bf16_kernel' if args.math == 'bf16' else 'gemm_f32_kernel'})",
+                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                "all_gemm": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                 "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                             for k, v in gemms.items()}}
+    out = {
+        "metric": "multimodal samples/sec/GPU (fwd+bwd) at batch 512; 1->8 GPU scaling",
+        "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: full 4-modality AppleCiDEr (image 3x63x63 + metadata 24 "
+                               "+ photometry 128x7 + spectra 4096), fwd+CE+bwd+Adam, dropout on",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "storage_dtype": "f32", "mfma_input_dtype": args.math, "final_loss": round(final_loss, 5)},
+        "roofline": roofline,
+    }
+    if "dwconv7x7_fwd" in ks:
+        d = ks["dwconv7x7_fwd"]
+        gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "dwconv7x7_fwd_kernel", "achieved": round(gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "traffic": None, "launches": d["launches"]}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import time_full_model
+        from oracle.weights import closed_form_state_dict
+        cb = make_batch(args.cpu_batch, seed=2)
+        cpu_model = AppleCider(dict(FUSION_CFG))
+        sd = closed_form_state_dict({k: v.shape for k, v in cpu_model.state_dict().items()})
+        ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": "avg", "lr": 1e-3,
+                "kernel_sizes_per_stage": default_config()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
+        res = time_full_model(sd, cb, ocfg, steps=2, warmup=1)
+        res["value"] = round(res["value"], 3)
+        res["ms_per_step"] = round(res["ms_per_step"], 1)
+        out["cpu_baseline"] = res
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

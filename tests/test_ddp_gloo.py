@@ -32,15 +32,21 @@ def _worker(rank, world, port, bucket_bytes, overlap, q):
     fp.flatten()
     broadcast_parameters(fp)
     gb = GradBuckets(fp, bucket_bytes=bucket_bytes, overlap=overlap)
+    import copy
+    ref_net = copy.deepcopy(net)  # same (broadcast) weights, no hooks: the purely local gradient
     outs = []
     for step in range(2):
         fp.zero_grad()
+        ref_net.zero_grad()
         gen = torch.Generator().manual_seed(1000 * rank + step)
         x = torch.randn(8, 16, generator=gen)
         net(x).square().mean().backward()
-        local = fp.grad.clone()
+        ref_net(x).square().mean().backward()
         gb.finish()
-        outs.append((local, fp.grad.clone(), fp.flat.clone()))
+        local = torch.cat([p.grad.reshape(-1) for p in ref_net.parameters()])
+        avg = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        assert unused.grad.abs().max() == 0
+        outs.append((local.numpy().copy(), avg.numpy().copy(), fp.flat.detach().numpy().copy()))
     q.put((rank, len(gb.buckets), outs))
     dist.barrier()
     dist.destroy_process_group()
@@ -65,8 +71,8 @@ def test_two_rank_gradient_average(bucket_bytes, overlap):
     if bucket_bytes == 256:
         assert res[0][0] > 1  # several buckets exercised
     for step in range(2):
-        l0, a0, w0 = res[0][1][step]
-        l1, a1, w1 = res[1][1][step]
+        l0, a0, w0 = (torch.from_numpy(t) for t in res[0][1][step])
+        l1, a1, w1 = (torch.from_numpy(t) for t in res[1][1][step])
         assert torch.equal(w0, w1)  # broadcast made the replicas identical
         want = (l0 + l1) / 2
         assert torch.allclose(a0, want, atol=1e-7) and torch.allclose(a1, want, atol=1e-7)
