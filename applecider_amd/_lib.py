@@ -57,7 +57,7 @@ SIGNATURES = {
     "ac_strerror": [_I32],
     "ac_gemm": [C.POINTER(GemmDesc), _P],
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P],
-    "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _P],
+    "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "ac_act_fwd": [_P, _P, _I64, _I32, _P],

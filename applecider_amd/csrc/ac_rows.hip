@@ -120,18 +120,118 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_kernel(
     }
 }
 
-// out[n] (+)= sum_m x[m, n]; a workgroup owns a slab of rows and all columns.
+// Register-resident LayerNorm backward for C % 4 == 0 and C <= 256*J: a wave owns a row, each lane
+// keeps J float4 of x / dy in registers (one HBM read of each), accumulates its channels' dgamma /
+// dbeta (and optionally the column sums of dx = the bias gradient of the producing conv/linear)
+// in registers over all the wave's rows, and the workgroup flushes once through LDS.
+template <int J>
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_reg_kernel(
+    const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
+    int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dxsum, int64_t rows, int C, int act) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [3][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * (ROWS_BLOCK / 64);
+    const float invC = 1.0f / (float)C;
+    f32x4 g4[J], b4[J], adg[J], adb[J], adx[J];
+    bool on[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = 4 * lane + 256 * j;
+        on[j] = c < C;
+        g4[j] = on[j] ? *(const f32x4 *)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[j] = (on[j] && beta) ? *(const f32x4 *)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = threadIdx.x; c < 3 * C; c += ROWS_BLOCK) sacc[c] = 0.f;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float mu = mean[r], rs = rstd[r];
+        f32x4 xh[J], d[J];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+                const int c = 4 * lane + 256 * j;
+                xh[j] = *(const f32x4 *)(x + r * ldx + c);
+                d[j] = *(const f32x4 *)(dy + r * lddy + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h = (xh[j][e] - mu) * rs;
+                    float dd = d[j][e];
+                    if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                    xh[j][e] = h;
+                    d[j][e] = dd;
+                    const float g = dd * g4[j][e];
+                    s1 += g;
+                    s2 += g * h;
+                    adg[j][e] += dd * h;
+                    adb[j][e] += dd;
+                }
+            }
+        }
+        const float c1 = ac_wave_sum(s1) * invC;
+        const float c2 = ac_wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = rs * (d[j][e] * g4[j][e] - c1 - xh[j][e] * c2);
+                    adx[j][e] += o[e];
+                }
+                *(f32x4 *)(dx + r * lddx + 4 * lane + 256 * j) = o;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (on[j]) {
+            const int c = 4 * lane + 256 * j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&sacc[c + e], adg[j][e]);
+                atomicAdd(&sacc[C + c + e], adb[j][e]);
+                if (dxsum) atomicAdd(&sacc[2 * C + c + e], adx[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += ROWS_BLOCK) {
+        if (dgamma) atomicAdd(&dgamma[c], sacc[c]);
+        if (dbeta) atomicAdd(&dbeta[c], sacc[C + c]);
+        if (dxsum) atomicAdd(&dxsum[c], sacc[2 * C + c]);
+    }
+}
+
+// out[n] += sum_m x[m, n]: a workgroup owns a slab of rows and a 64-column strip; thread =
+// (column, one of 4 row phases) so that narrow matrices still use every lane; each wave reads
+// 256 contiguous bytes per row.
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int64_t ldx,
                                                      float *__restrict__ out, int64_t rows,
                                                      int cols, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += x[r * ldx + c];
-        atomicAdd(&out[c], s);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int64_t r = r0 + ph;
+        for (; r + 4 < r1; r += 8) {
+            s0 += x[r * ldx + c];
+            s1 += x[(r + 4) * ldx + c];
+        }
+        if (r < r1) s0 += x[r * ldx + c];
     }
+    part[ph][cl] = s0 + s1;
+    __syncthreads();
+    if (ph == 0 && c < cols) atomicAdd(&out[c], (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
 }
 
 __global__ __launch_bounds__(ROWS_BLOCK) void l2norm_fwd_kernel(const float *__restrict__ x,
@@ -288,17 +388,36 @@ extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
 extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                                 const float *mean, const float *rstd, const float *gamma,
                                 const float *beta, float *dx, int64_t lddx, float *dgamma,
-                                float *dbeta, int64_t rows, int32_t C, int32_t act,
-                                ac_stream_t stream) {
+                                float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
+                                ac_stream_t stream_) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || rows < 0 || C <= 0) return AC_EINVAL;
     if (act == AC_ACT_GELU && !beta) return AC_EINVAL;
     if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
-    if (C > 8192) return AC_EINVAL;  // 2*C floats of LDS
+    if (C > 4096) return AC_EINVAL;  // 3*C floats of LDS
     if (rows == 0) return AC_OK;
-    const int grid = grid_for_rows(rows, 64, 1024);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_BLOCK),
-                       2 * (size_t)C * sizeof(float), (hipStream_t)stream, dy, lddy, x, ldx, mean,
-                       rstd, gamma, beta, dx, lddx, dgamma, dbeta, rows, C, act);
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool vec = (C % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) &&
+                     ac_aligned16(dy) && ac_aligned16(x) && ac_aligned16(dx) &&
+                     ac_aligned16(gamma) && (!beta || ac_aligned16(beta)) && C <= 1536;
+    const size_t lds = 3 * (size_t)C * sizeof(float);
+    if (vec) {
+        const int grid = grid_for_rows(rows, 16, 2048);
+#define LN_BWD(JJ)                                                                              \
+    hipLaunchKernelGGL(layernorm_bwd_reg_kernel<JJ>, dim3(grid), dim3(ROWS_BLOCK), lds, stream, \
+                       dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma, dbeta,      \
+                       dxsum, rows, C, act)
+        if (C <= 256) LN_BWD(1);
+        else if (C <= 512) LN_BWD(2);
+        else if (C <= 768) LN_BWD(3);
+        else LN_BWD(6);
+#undef LN_BWD
+    } else {
+        if (dxsum) return AC_EINVAL;  // fused bias gradient only on the vector path
+        const int grid = grid_for_rows(rows, 64, 1024);
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_BLOCK),
+                           2 * (size_t)C * sizeof(float), stream, dy, lddy, x, ldx, mean, rstd,
+                           gamma, beta, dx, lddx, dgamma, dbeta, rows, C, act);
+    }
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -311,11 +430,11 @@ extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, 
         if (e != hipSuccess) return -(int)e - 2000;
     }
     if (rows == 0) return AC_OK;
-    int rpb = 128;
-    while ((rows + rpb - 1) / rpb > 8192) rpb *= 2;
-    const int grid = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, out,
-                       rows, cols, rpb);
+    int rpb = 256;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows,
+                       cols, rpb);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

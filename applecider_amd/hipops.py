@@ -207,7 +207,7 @@ class _LayerNorm(Function):
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
-                                            _p(beta), _p(dx), Cn, _p(dg), _p(db), rows, Cn,
+                                            _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
                                             ctx.act, _stream()), "ac_layernorm_bwd")
         return dx, dg, db, None, None
 
@@ -619,11 +619,14 @@ class _ConvGroup1d(Function):
     just an overlapping-row view (row stride Cin).  For Cin == 1 the rows would be 4-byte
     shifted; there the 8 residues l%8 become 8 shifted copies of the filter instead
     (Toeplitz trick) so that A rows are 32-byte strided.
-    args: x, ksizes(tuple), w0, b0, w1, b1, ...
+    With ln_gamma/ln_beta the LayerNorm over the 3*Cout channels + GELU of spectranet.py:31-35 is
+    applied in the same autograd node, and its backward kernel also emits the column sums of
+    d(ycat) — the three bias gradients — so no separate pass over the [B*L, 3*Cout] gradient.
+    args: x, ksizes(tuple), ln_gamma, ln_beta, ln_eps, w0, b0, w1, b1, ...
     """
 
     @staticmethod
-    def forward(ctx, x, ksizes, *wb):
+    def forward(ctx, x, ksizes, ln_gamma, ln_beta, ln_eps, *wb):
         x = _chk(x, "x")
         B, L, Cin = x.shape
         ws = [_chk(w, "w") for w in wb[0::2]]
@@ -667,7 +670,6 @@ class _ConvGroup1d(Function):
                 saved_meta.append((base, shift, Kp, goff_c))
             ctx.meta = saved_meta
             ctx.Lp = Lp
-            ctx.save_for_backward(xpad, *ws)
         else:
             if Cin % 32:
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
@@ -679,18 +681,52 @@ class _ConvGroup1d(Function):
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(ws[j]), k * Cin), mat(_p(ycat, j * Cout), Ncat), bias=bs[j])
             ctx.Lp = Lp
-            ctx.save_for_backward(xpad, *ws)
+        ctx.fused_ln = ln_gamma is not None
+        if ctx.fused_ln:
+            rows = B * L
+            y = torch.empty_like(ycat)
+            mean = torch.empty(rows, device=dev, dtype=torch.float32)
+            rstd = torch.empty(rows, device=dev, dtype=torch.float32)
+            _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), _p(y), Ncat,
+                                                _p(mean), _p(rstd), rows, Ncat, ln_eps, ACT_GELU,
+                                                _stream()), "ac_layernorm_fwd")
+            ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta)
+            return y
+        ctx.save_for_backward(xpad, *ws)
         return ycat
 
     @staticmethod
     def backward(ctx, dycat):
-        xpad, *ws = ctx.saved_tensors
         B, L, Cin, Cout, Pmax = ctx.dims
         ksizes = ctx.ksizes
         nconv = len(ksizes)
         Ncat = nconv * Cout
         dev = dycat.device
         dycat = _chk(dycat, "dycat")
+        dgam = dbet = bias_sums = None
+        if ctx.fused_ln:
+            saved = ctx.saved_tensors
+            xpad, ws = saved[0], list(saved[1:1 + nconv])
+            ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:]
+            dpre = torch.empty_like(ycat)
+            dgam, dbet = torch.zeros_like(ln_gamma), torch.zeros_like(ln_beta)
+            fuse_bias = Ncat % 4 == 0 and Ncat <= 1536
+            bias_sums = torch.zeros(Ncat, device=dev, dtype=torch.float32) if fuse_bias else None
+            _lib.check(_lib_().ac_layernorm_bwd(_p(dycat), Ncat, _p(ycat), Ncat, _p(mean), _p(rstd),
+                                                _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
+                                                _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
+                                                _stream()), "ac_layernorm_bwd")
+            dycat = dpre
+        else:
+            xpad, *ws = ctx.saved_tensors
+
+        def bias_grad(j):
+            if not ctx.has_b[j]:
+                return None
+            if bias_sums is not None:
+                return bias_sums[j * Cout:(j + 1) * Cout]
+            return colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev)
+
         Lp = ctx.Lp
         grads = []
         dx = None
@@ -705,8 +741,7 @@ class _ConvGroup1d(Function):
                 dw = torch.empty(Cout, k, device=dev, dtype=torch.float32)
                 _lib.check(_lib_().ac_toeplitz_fold(_p(dwexp), _p(dw), Cout, k, Kp, shift,
                                                     _stream()), "ac_toeplitz_fold")
-                db = colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev) if ctx.has_b[j] else None
-                grads += [dw, db]
+                grads += [dw, bias_grad(j)]
             if ctx.needs_input_grad[0]:
                 raise NotImplementedError("input gradient of the Cin == 1 conv bank is not needed "
                                           "on the path (the flux is a network input)")
@@ -731,16 +766,17 @@ class _ConvGroup1d(Function):
                 gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dycat, j * Cout), Ncat),
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L))
-                db = colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev) if ctx.has_b[j] else None
-                grads += [dw, db]
-        return (dx, None, *grads)
+                grads += [dw, bias_grad(j)]
+        return (dx, None, dgam, dbet, None, *grads)
 
 
-def conv_group1d(x, ksizes, weights, biases):
+def conv_group1d(x, ksizes, weights, biases, ln=None):
+    """ln = (gamma, beta, eps) fuses LayerNorm + GELU over the concatenated channels."""
     args = []
     for w, b in zip(weights, biases):
         args += [w, b]
-    return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), *args)
+    g, bt, eps = ln if ln is not None else (None, None, 0.0)
+    return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), g, bt, float(eps), *args)
 
 
 # --------------------------------------------------------------------------- photometry branch

@@ -42,8 +42,8 @@ class SpectraNetBlock(nn.Module):
 
     def forward(self, x):  # x: [B, L, Cin] channels-last
         y = H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs],
-                           [c.bias for c in self.convs])
-        y = self.norm(y, act="gelu")
+                           [c.bias for c in self.convs],
+                           ln=(self.norm.weight, self.norm.bias, self.norm.eps))
         if self.do_pool:
             y = H.maxpool4(self.downsample(y))
         return y

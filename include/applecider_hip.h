@@ -118,15 +118,17 @@ int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
  * spectranet.py:21,31; HyraxBaselineCLS.py:34 and the two norms inside each
  * nn.TransformerEncoderLayer; timm ConvNeXt block norm / LayerNorm2d in NHWC).
  * act = AC_ACT_GELU fuses the GELU of spectranet.py:35 (y = gelu(ln(x))).
- * bwd accumulates dgamma/dbeta with atomics: zero them first.
+ * bwd accumulates dgamma/dbeta with atomics: zero them first.  dxsum (nullable, C % 4 == 0 and
+ * C <= 1536 only) additionally accumulates the column sums of dx, i.e. the bias gradient of the
+ * conv/linear that produced x, so that no separate pass over dx is needed.
  * ---------------------------------------------------------------------- */
 int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
                      float *y, int64_t ldy, float *mean, float *rstd, int64_t rows, int32_t C,
                      float eps, int32_t act, ac_stream_t stream);
 int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
-                     float *dx, int64_t lddx, float *dgamma, float *dbeta, int64_t rows,
-                     int32_t C, int32_t act, ac_stream_t stream);
+                     float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
+                     int64_t rows, int32_t C, int32_t act, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Elementwise / reduction helpers.

@@ -147,7 +147,8 @@ def test_linear_residual_colscale(dev):
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("rows,C", [(1000, 96), (333, 192), (64, 3072), (512, 5), (100, 130)])
+@pytest.mark.parametrize("rows,C", [(1000, 96), (333, 192), (64, 3072), (512, 5), (100, 130), (5000, 384),
+                                    (700, 768), (300, 1536), (2000, 16), (9, 288)])
 @pytest.mark.parametrize("act", [None, "gelu"])
 def test_layernorm(dev, rows, C, act):
     from applecider_amd import hipops as H
@@ -263,21 +264,28 @@ def test_pools(dev):
 
 
 # ----------------------------------------------------------------------------- spectra conv bank
+@pytest.mark.parametrize("fused_ln", [False, True])
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 1, 64, (3, 61, 1021)), (3, 64, 1, 32, (3, 7, 13)),
                                              (2, 128, 64, 128, (3, 31, 251)), (2, 16, 32, 64, (3, 7, 13)),
-                                             (1, 64, 128, 32, (3, 15, 61))])
-def test_conv_group1d(dev, B, L, Cin, Cout, ks):
+                                             (1, 64, 128, 32, (3, 15, 61)), (4, 64, 256, 512, (3, 11, 31)),
+                                             (2, 16, 512, 1024, (3, 7, 13))])
+def test_conv_group1d(dev, B, L, Cin, Cout, ks, fused_ln):
     from applecider_amd import hipops as H
     x = g(dev, B, Cin, L, seed=1).requires_grad_(Cin != 1)
     ws = [(g(dev, Cout, Cin, k, seed=10 + i) / math.sqrt(Cin * k)).requires_grad_() for i, k in enumerate(ks)]
     bs = [g(dev, Cout, seed=20 + i).requires_grad_() for i in range(len(ks))]
+    lw = (1 + 0.1 * g(dev, 3 * Cout, seed=30)).requires_grad_()
+    lb = (0.1 * g(dev, 3 * Cout, seed=31)).requires_grad_()
     y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)  # [B, 3Cout, L]
+    if fused_ln:
+        y = F.gelu(F.layer_norm(y.permute(0, 2, 1), (3 * Cout,), lw, lb, 1e-5)).permute(0, 2, 1)
     go = g(dev, *y.shape, seed=5)
     y.backward(go)
     xd = x.detach().permute(0, 2, 1).contiguous().to(dev).requires_grad_(Cin != 1)
     wd = [w.detach().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
     bd = [b.detach().to(dev).requires_grad_() for b in bs]
-    yd = H.conv_group1d(xd, ks, wd, bd)
+    lwd, lbd = lw.detach().to(dev).requires_grad_(), lb.detach().to(dev).requires_grad_()
+    yd = H.conv_group1d(xd, ks, wd, bd, ln=(lwd, lbd, 1e-5) if fused_ln else None)
     yd.backward(go.permute(0, 2, 1).contiguous().to(dev))
     close(yd.permute(0, 2, 1), y, name="y")
     for i, k in enumerate(ks):
@@ -285,6 +293,9 @@ def test_conv_group1d(dev, B, L, Cin, Cout, ks):
         close(bd[i].grad, bs[i].grad, name=f"db{i}")
     if Cin != 1:
         close(xd.grad.permute(0, 2, 1), x.grad, name="dx")
+    if fused_ln:
+        close(lwd.grad, lw.grad, name="dgamma")
+        close(lbd.grad, lb.grad, name="dbeta")
 
 
 # ----------------------------------------------------------------------------- photometry branch
