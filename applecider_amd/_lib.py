@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
 
 AC_GEMM_NT, AC_GEMM_NN, AC_GEMM_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-MATH_F32, MATH_BF16 = 0, 1
+MATH_F32, MATH_BF16, MATH_BF16_IN = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU,
              "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH}
 
@@ -56,6 +56,8 @@ SIGNATURES = {
     "ac_abi_version": [],
     "ac_strerror": [_I32],
     "ac_gemm": [C.POINTER(GemmDesc), _P],
+    "ac_cast_bf16": [_P, _P, _I64, _P],
+    "ac_transpose_cast_bf16": [_P, _I64, _P, _I64, _I64, _I32, _P],
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],

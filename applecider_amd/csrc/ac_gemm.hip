@@ -399,6 +399,243 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// bf16-OPERAND kernels (math = AC_MATH_BF16_IN): A and B are already bf16 in HBM (cast once per
+// call by ac_cast_bf16 / ac_transpose_cast_bf16, so the K-fold re-reads of the implicit-GEMM
+// operands move half the bytes and the inner loop carries no conversion).  Tile 128x128x64,
+// 4 waves, 16 MFMA 32x32x16 per wave per K-tile, double-buffered LDS, register staging.
+//   NT: both operands "KC" ([128 rows][64 k] bf16 = 128-byte rows, the same chunk swizzle as the
+//       fp32 image; one ds_read_b128 = one MFMA operand).
+//   TN: both operands "RC" ([64 k][128 cols] bf16, row pitch 320 B); MFMA operands are gathered
+//       with the hardware transpose read ds_read_b64_tr_b16 (two per operand), bank-conflict free
+//       at that pitch.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK16 = 64;
+constexpr int KC16_TILE = 128 * 64;   // ushort elements (16 KB)
+constexpr int RC16_PITCH = 160;       // ushort elements (320 B)
+constexpr int RC16_TILE = 64 * RC16_PITCH;  // 20 KB
+
+struct LoaderKC16 {
+    const unsigned short *ptr;
+    const int32_t *goff;
+    int64_t base[4];
+    int inner_n, t;
+    __device__ __forceinline__ void init(const ac_mat &m, int outer_n, int inner_extent, int origin,
+                                         int tid) {
+        ptr = (const unsigned short *)m.ptr;
+        goff = m.goff;
+        inner_n = inner_extent;
+        t = tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = origin + (t >> 3) + 32 * i;
+            r = r < outer_n ? r : outer_n - 1;
+            base[i] = ac_rowaddr(m.rows, r);
+        }
+    }
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[4]) const {
+        const int e = kt * BK16 + 8 * (t & 7);
+        const bool kv = e < inner_n;
+        const int64_t ko = goff ? (int64_t)goff[e >> 5] + (e & 31) : (int64_t)e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (kv)
+                v[i] = *(const u32x4 *)(ptr + base[i] + ko);
+            else
+                v[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[4]) const {
+        const int c = t & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (t >> 3) + 32 * i;
+            *(u32x4 *)(tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = v[i];
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 frag_kc16(const unsigned short *tile, int local, int s, int lh) {
+    const int chunk = (2 * s + lh) ^ ((local >> 1) & 7);
+    return *(const bf16x8 *)(tile + local * 64 + (chunk << 3));
+}
+
+struct LoaderRC16 {
+    const unsigned short *ptr;
+    ac_rowmap rows;
+    int64_t io;
+    bool cv;
+    int outer_n, t;
+    __device__ __forceinline__ void init(const ac_mat &m, int outer_extent, int inner_extent,
+                                         int origin, int tid) {
+        ptr = (const unsigned short *)m.ptr;
+        rows = m.rows;
+        outer_n = outer_extent;
+        t = tid;
+        const int col = origin + 8 * (t & 15);
+        cv = col < inner_extent;
+        io = cv ? (m.goff ? (int64_t)m.goff[col >> 5] + (col & 31) : (int64_t)col) : 0;
+    }
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kg = kt * BK16 + (t >> 4) + 16 * i;
+            if (cv && kg < outer_n)
+                v[i] = *(const u32x4 *)(ptr + ac_rowaddr(rows, kg) + io);
+            else
+                v[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = (t >> 4) + 16 * i;
+            *(u32x4 *)(tile + k * RC16_PITCH + 8 * (t & 15)) = v[i];
+        }
+    }
+};
+
+// MFMA operand (8 consecutive k of column `local`) from an RC image via two transpose reads.
+// Lane l: 16-lane group g = l>>4 covers columns 16*(g&1).. and k half (g>>1) = l>>5; lane 4q+p of
+// the group addresses row q, columns 4p..4p+3 of the 4x16 block and receives column (l&15).
+__device__ __forceinline__ bf16x8 frag_rc16(const unsigned short *tile, int colbase, int s, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int k0 = 16 * s + 8 * (g >> 1);
+    const unsigned short *a0 = tile + (k0 + q) * RC16_PITCH + colbase + 16 * (g & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * RC16_PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <bool TN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short *sm = reinterpret_cast<unsigned short *>(smem);
+    constexpr int TILE = TN ? RC16_TILE : KC16_TILE;
+    const ac_gemm_desc &d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
+
+    const int kt_begin = blockIdx.y * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split;
+    if (kt_end > p.nkt) kt_end = p.nkt;
+    if (kt_begin >= kt_end) return;
+
+    typename std::conditional<TN, LoaderRC16, LoaderKC16>::type la, lb;
+    if (TN) {
+        la.init(d.a, d.K, d.M, tm * BM, t);
+        lb.init(d.b, d.K, d.N, tn * BN, t);
+    } else {
+        la.init(d.a, d.M, d.K, tm * BM, t);
+        lb.init(d.b, d.N, d.K, tn * BN, t);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u32x4 ra[4], rb[4];
+    la.load(kt_begin, ra);
+    lb.load(kt_begin, rb);
+    la.store(sm, ra);
+    lb.store(sm + TILE, rb);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) {
+            la.load(kt + 1, ra);
+            lb.load(kt + 1, rb);
+        }
+        const unsigned short *at = sm + cur * 2 * TILE, *bt = at + TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a0, a1, b0, b1;
+            if (TN) {
+                a0 = frag_rc16(at, wm * 64, s, lane);
+                a1 = frag_rc16(at, wm * 64 + 32, s, lane);
+                b0 = frag_rc16(bt, wn * 64, s, lane);
+                b1 = frag_rc16(bt, wn * 64 + 32, s, lane);
+            } else {
+                a0 = frag_kc16(at, wm * 64 + li, s, lh);
+                a1 = frag_kc16(at, wm * 64 + 32 + li, s, lh);
+                b0 = frag_kc16(bt, wn * 64 + li, s, lh);
+                b1 = frag_kc16(bt, wn * 64 + 32 + li, s, lh);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            la.store(sm + (cur ^ 1) * 2 * TILE, ra);
+            lb.store(sm + (cur ^ 1) * 2 * TILE + TILE, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_tile(d, acc, tm, tn, wm, wn, li, lh);
+}
+
+// fp32 -> bf16 (round to nearest even), 8 elements per thread
+__global__ void cast_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ y,
+                                 int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4 *)(x + 8 * i), b = *(const f32x4 *)(x + 8 * i + 4);
+        bf16x8 o;
+        o[0] = (short)f2bf(a[0]); o[1] = (short)f2bf(a[1]); o[2] = (short)f2bf(a[2]); o[3] = (short)f2bf(a[3]);
+        o[4] = (short)f2bf(b[0]); o[5] = (short)f2bf(b[1]); o[6] = (short)f2bf(b[2]); o[7] = (short)f2bf(b[3]);
+        *(bf16x8 *)(y + 8 * i) = o;
+    }
+}
+__global__ void cast_bf16_tail_kernel(const float *__restrict__ x, unsigned short *__restrict__ y,
+                                      int64_t begin, int64_t n) {
+    int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f2bf(x[i]);
+}
+
+// y[c, r] = bf16(x[r, c]) through a 64x64 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float *__restrict__ x,
+                                                                  int64_t ldx,
+                                                                  unsigned short *__restrict__ y,
+                                                                  int64_t ldy, int64_t rows,
+                                                                  int cols) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t rr = r0 + i;
+        const int cc = c0 + tx;
+        tile[i][tx] = (rr < rows && cc < cols) ? x[rr * ldx + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int cc = c0 + i;
+        const int64_t rr = r0 + tx;
+        if (cc < cols && rr < rows) y[(int64_t)cc * ldy + rr] = f2bf(tile[tx][i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Scalar kernel for tiny or unaligned products (metadata towers, router, class
 // heads: K, N of 2..48).  One thread per output element.
 // ---------------------------------------------------------------------------
@@ -444,6 +681,38 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     if (d.c.rows.r1 != 0 && d.c.rows.r2 == 0) return AC_EINVAL;
     if (d.split_k < 1) d.split_k = 1;
 
+    if (d.math == AC_MATH_BF16_IN) {
+        // operands are bf16 in memory: strides / offsets in bf16 elements, multiples of 8 (16 B)
+        if (d.mode == AC_GEMM_NN) return AC_EINVAL;  // transpose B at cast time and use NT
+        auto al8 = [](const ac_rowmap &r) { return r.s1 % 8 == 0 && r.s2 % 8 == 0 && r.s3 % 8 == 0; };
+        const int ai = d.mode == AC_GEMM_TN ? d.M : d.K, bi = d.mode == AC_GEMM_TN ? d.N : d.K;
+        if (!ac_aligned16(d.a.ptr) || !ac_aligned16(d.b.ptr) || !al8(d.a.rows) || !al8(d.b.rows) ||
+            (ai % 8) || (bi % 8) || d.force_simple)
+            return AC_EALIGN;
+        GemmParams p;
+        p.d = d;
+        if (d.split_k > 1) p.d.accumulate = 2;
+        if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
+        p.tiles_m = (d.M + BM - 1) / BM;
+        p.tiles_n = (d.N + BN - 1) / BN;
+        p.nkt = (d.K + BK16 - 1) / BK16;
+        p.kt_per_split = (p.nkt + d.split_k - 1) / d.split_k;
+        dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
+        if (d.mode == AC_GEMM_TN) {
+            // 80 KB of dynamic LDS (two double-buffered 20 KB images): above the 64 KB default
+            static const hipError_t attr = hipFuncSetAttribute(
+                (const void *)gemm_bf16in_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                4 * RC16_TILE * (int)sizeof(short));
+            if (attr != hipSuccess) return -(int)attr - 2000;
+            hipLaunchKernelGGL((gemm_bf16in_kernel<true>), grid, dim3(256),
+                               4 * RC16_TILE * sizeof(short), stream, p);
+        }
+        else
+            hipLaunchKernelGGL((gemm_bf16in_kernel<false>), grid, dim3(256),
+                               4 * KC16_TILE * sizeof(short), stream, p);
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
     const bool a_kc = d.mode != AC_GEMM_TN;
     const bool b_kc = d.mode == AC_GEMM_NT;
     // inner extents must be multiples of 4 so that 16-byte chunks never straddle the edge
@@ -490,6 +759,35 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         else
             hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), lds_f32, stream, p);
     }
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream) {
+    if (!x || !y || n < 0) return AC_EINVAL;
+    if (n == 0) return AC_OK;
+    const int64_t n8 = (ac_aligned16(x) && ac_aligned16(y)) ? n / 8 : 0;
+    if (n8 > 0) {
+        int64_t g = (n8 + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x,
+                           (unsigned short *)y, n8);
+    }
+    if (8 * n8 < n) {
+        const int64_t rem = n - 8 * n8;
+        hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3((int)((rem + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, (unsigned short *)y, 8 * n8, n);
+    }
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int64_t ldy,
+                                      int64_t rows, int32_t cols, ac_stream_t stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return AC_EINVAL;
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+    hipLaunchKernelGGL(transpose_cast_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (unsigned short *)y, ldy, rows, cols);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

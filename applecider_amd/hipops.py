@@ -80,6 +80,30 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     _lib.check(_lib_().ac_gemm(C.byref(d), _stream()), "ac_gemm")
 
 
+def bf16_operands() -> bool:
+    """bf16 mode stages GEMM operands as bf16 copies in HBM (cast once per call) when shapes allow."""
+    return _MATH == _lib.MATH_BF16
+
+
+def cast16(t: torch.Tensor) -> torch.Tensor:
+    y = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    _lib.check(_lib_().ac_cast_bf16(_p(t), _p(y), t.numel(), _stream()), "ac_cast_bf16")
+    return y
+
+
+def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
+    """[R, C] fp32 -> [C, R] bf16."""
+    R, Cc = t2d.shape
+    y = torch.empty(Cc, R, device=t2d.device, dtype=torch.bfloat16)
+    _lib.check(_lib_().ac_transpose_cast_bf16(_p(t2d), Cc, _p(y), R, R, Cc, _stream()),
+               "ac_transpose_cast_bf16")
+    return y
+
+
+def _big(M, N, K) -> bool:
+    return float(M) * N * K >= 262144.0
+
+
 def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     tiles = -(-m_out // 128) * -(-n_out // 128)
     nkt = -(-k_red // 32)
@@ -133,8 +157,15 @@ class _Linear(Function):
         save_pre = need_grad and (act == ACT_GELU or (act == ACT_RELU and residual is not None)
                                   or colscale is not None)
         pre = torch.empty_like(y) if save_pre else None
-        gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
-             pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N)
+        ctx.b16 = bf16_operands() and K % 8 == 0 and N % 8 == 0 and _big(M, N, K)
+        if ctx.b16:
+            x16, w16 = cast16(x2), cast16(w)
+            gemm(AC_GEMM_NT, M, N, K, mat(_p(x16), K), mat(_p(w16), K), mat(_p(y), N), bias=b,
+                 act=act, pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
+                 math=_lib.MATH_BF16_IN)
+        else:
+            gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
+                 pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.shape_x = x.shape
         ctx.has_b = b is not None
@@ -161,14 +192,25 @@ class _Linear(Function):
             _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
                        "ac_act_bwd")
         dx = dw = db = None
+        g16 = cast16(g) if ctx.b16 else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
+            if ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
+                wT16 = cast16_T(w)
+                gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
+                     math=_lib.MATH_BF16_IN)
+            else:
+                gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
             dx = dx.reshape(ctx.shape_x)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
-            gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
-                 accumulate=2, split_k=_split_for(N, K, M))
+            if ctx.b16:
+                x16 = cast16(x2)
+                gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(x16), K), mat(_p(dw), K),
+                     accumulate=2, split_k=_split_for(N, K, M), math=_lib.MATH_BF16_IN)
+            else:
+                gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
+                     accumulate=2, split_k=_split_for(N, K, M))
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = colsum(_p(g), N, M, N, dy.device)
         dres = dy if ctx.has_res else None
@@ -490,8 +532,14 @@ class _PatchConv2x2(Function):
                                for cb in range(Cn // 32)], x.device)
         amap = dict(r1=OH * OW, s1=H * W_ * Cn, r2=OW, s2=2 * W_ * Cn, s3=2 * Cn)
         y = torch.empty(M, Cout, device=x.device, dtype=torch.float32)
-        gemm(AC_GEMM_NT, M, Cout, 4 * Cn, mat(_p(x), goff=goff, **amap), mat(_p(w), 4 * Cn),
-             mat(_p(y), Cout), bias=b)
+        ctx.b16 = bf16_operands() and Cout % 8 == 0
+        if ctx.b16:
+            x16, w16 = cast16(x), cast16(w)  # keep both alive until the launch is enqueued
+            gemm(AC_GEMM_NT, M, Cout, 4 * Cn, mat(_p(x16), goff=goff, **amap),
+                 mat(_p(w16), 4 * Cn), mat(_p(y), Cout), bias=b, math=_lib.MATH_BF16_IN)
+        else:
+            gemm(AC_GEMM_NT, M, Cout, 4 * Cn, mat(_p(x), goff=goff, **amap), mat(_p(w), 4 * Cn),
+                 mat(_p(y), Cout), bias=b)
         ctx.save_for_backward(x, w, goff)
         ctx.amap, ctx.has_b = amap, b is not None
         return y.reshape(B, OH, OW, Cout)
@@ -505,14 +553,26 @@ class _PatchConv2x2(Function):
         M = B * OH * OW
         dy2 = _chk(dy, "dy").reshape(M, Cout)
         dx = dw = db = None
+        dy16 = cast16(dy2) if ctx.b16 else None
         if ctx.needs_input_grad[0]:
             dx = torch.zeros_like(x)  # border pixels dropped by the stride get zero gradient
-            gemm(AC_GEMM_NN, M, 4 * Cn, Cout, mat(_p(dy2), Cout), mat(_p(w), 4 * Cn),
-                 mat(_p(dx), goff=goff, **ctx.amap))
+            if ctx.b16:
+                wT16 = cast16_T(w)
+                gemm(AC_GEMM_NT, M, 4 * Cn, Cout, mat(_p(dy16), Cout), mat(_p(wT16), Cout),
+                     mat(_p(dx), goff=goff, **ctx.amap), math=_lib.MATH_BF16_IN)
+            else:
+                gemm(AC_GEMM_NN, M, 4 * Cn, Cout, mat(_p(dy2), Cout), mat(_p(w), 4 * Cn),
+                     mat(_p(dx), goff=goff, **ctx.amap))
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
-            gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy2), Cout), mat(_p(x), goff=goff, **ctx.amap),
-                 mat(_p(dw), 4 * Cn), accumulate=2, split_k=_split_for(Cout, 4 * Cn, M))
+            if ctx.b16:
+                x16 = cast16(x)
+                gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy16), Cout),
+                     mat(_p(x16), goff=goff, **ctx.amap), mat(_p(dw), 4 * Cn), accumulate=2,
+                     split_k=_split_for(Cout, 4 * Cn, M), math=_lib.MATH_BF16_IN)
+            else:
+                gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy2), Cout), mat(_p(x), goff=goff, **ctx.amap),
+                     mat(_p(dw), 4 * Cn), accumulate=2, split_k=_split_for(Cout, 4 * Cn, M))
         if ctx.has_b:
             db = colsum(_p(dy2), Cout, M, Cout, dy.device)
         return dx, dw, db
@@ -644,18 +704,23 @@ class _ConvGroup1d(Function):
         ycat = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
         ctx.ksizes, ctx.dims = tuple(ksizes), (B, L, Cin, Cout, Pmax)
         ctx.has_b = [b is not None for b in bs]
+        b16 = ctx.b16 = bf16_operands()
+        mth = _lib.MATH_BF16_IN if b16 else None
         if Cin == 1:
             if L % 8:
                 raise ValueError("Cin == 1 path needs L % 8 == 0")
-            Lp = (L + 2 * Pmax + 48 + 3) // 4 * 4
+            al = 8 if b16 else 4  # 16-byte granules in operand elements
+            Lp = (L + 2 * Pmax + 48 + 7) // 8 * 8
             xpad = _pad_rows(x, B, L, 1, Pmax, Lp)
+            if b16:
+                xpad = cast16(xpad)
             Lq = L // 8
             saved_meta = []
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
-                shift = off % 4
+                shift = off % al
                 base = off - shift
-                Kp = (k + 7 + shift + 3) // 4 * 4
+                Kp = (k + 7 + shift + al - 1) // al * al
                 wexp = torch.empty(8 * Cout, Kp, device=dev, dtype=torch.float32)
                 _lib.check(_lib_().ac_toeplitz_expand(_p(ws[j]), _p(wexp), Cout, k, Kp, shift,
                                                       _stream()), "ac_toeplitz_expand")
@@ -664,9 +729,11 @@ class _ConvGroup1d(Function):
                                              for cb in range(Cout // 32)], dev)
                 # bias[(r,co)] = b[co]; 8*Cout floats of plumbing
                 bexp = bs[j].detach().repeat(8) if bs[j] is not None else None
+                wop = cast16(wexp) if b16 else wexp
                 gemm(AC_GEMM_NT, B * Lq, 8 * Cout, Kp,
-                     mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(wexp), Kp),
-                     mat(_p(ycat), 8 * Ncat, goff=goff_c), bias=bexp)
+                     mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8),
+                     mat(_p(wop), Kp),
+                     mat(_p(ycat), 8 * Ncat, goff=goff_c), bias=bexp, math=mth)
                 saved_meta.append((base, shift, Kp, goff_c))
             ctx.meta = saved_meta
             ctx.Lp = Lp
@@ -675,11 +742,15 @@ class _ConvGroup1d(Function):
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
             Lp = L + 2 * Pmax
             xpad = _pad_rows(x, B, L, Cin, Pmax, Lp)
+            if b16:
+                xpad = cast16(xpad)
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
+                wop = cast16(ws[j]) if b16 else ws[j]
                 gemm(AC_GEMM_NT, B * L, Cout, k * Cin,
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
-                     mat(_p(ws[j]), k * Cin), mat(_p(ycat, j * Cout), Ncat), bias=bs[j])
+                     mat(_p(wop), k * Cin),
+                     mat(_p(ycat, j * Cout), Ncat), bias=bs[j], math=mth)
             ctx.Lp = Lp
         ctx.fused_ln = ln_gamma is not None
         if ctx.fused_ln:
@@ -730,14 +801,17 @@ class _ConvGroup1d(Function):
         Lp = ctx.Lp
         grads = []
         dx = None
+        b16 = ctx.b16
+        mth = _lib.MATH_BF16_IN if b16 else None
+        dyop = cast16(dycat) if b16 else dycat  # A operand of the dW products
         if Cin == 1:
             Lq = L // 8
             for j, k in enumerate(ksizes):
                 base, shift, Kp, goff_c = ctx.meta[j]
                 dwexp = torch.zeros(8 * Cout, Kp, device=dev, dtype=torch.float32)
-                gemm(AC_GEMM_TN, 8 * Cout, Kp, B * Lq, mat(_p(dycat), 8 * Ncat, goff=goff_c),
+                gemm(AC_GEMM_TN, 8 * Cout, Kp, B * Lq, mat(_p(dyop), 8 * Ncat, goff=goff_c),
                      mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(dwexp), Kp),
-                     accumulate=2, split_k=_split_for(8 * Cout, Kp, B * Lq))
+                     accumulate=2, split_k=_split_for(8 * Cout, Kp, B * Lq), math=mth)
                 dw = torch.empty(Cout, k, device=dev, dtype=torch.float32)
                 _lib.check(_lib_().ac_toeplitz_fold(_p(dwexp), _p(dw), Cout, k, Kp, shift,
                                                     _stream()), "ac_toeplitz_fold")
@@ -749,6 +823,8 @@ class _ConvGroup1d(Function):
             if ctx.needs_input_grad[0]:
                 Lpd = L + 2 * Pmax
                 dypad = _pad_rows(dycat, B, L, Ncat, Pmax, Lpd)
+                if b16:
+                    dypad = cast16(dypad)
                 dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
             for j, k in enumerate(ksizes):
                 p = k // 2
@@ -758,14 +834,27 @@ class _ConvGroup1d(Function):
                                   lambda j=j, k=k, p=p: [(Pmax + p - t) * Ncat + j * Cout + cb * 32
                                                          for t in range(k)
                                                          for cb in range(Cout // 32)], dev)
-                    gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
-                         mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
-                         mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
-                         mat(_p(dx), Cin), accumulate=0 if j == 0 else 1)
+                    if b16:
+                        # NT against the k-contiguous copy of the taps: wT[(t,ci), co]; operand row ci,
+                        # inner index (t, co) through an offset table
+                        wT = cast16_T(ws[j])  # [k*Cin, Cout]
+                        goff_b = _table(("cg_dxw", Cin, Cout, k),
+                                        lambda k=k: [t * Cin * Cout + cb * 32 for t in range(k)
+                                                     for cb in range(Cout // 32)], dev)
+                        gemm(AC_GEMM_NT, B * L, Cin, k * Cout,
+                             mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
+                             mat(_p(wT), Cout, goff=goff_b), mat(_p(dx), Cin),
+                             accumulate=0 if j == 0 else 1, math=mth)
+                    else:
+                        gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
+                             mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
+                             mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
+                             mat(_p(dx), Cin), accumulate=0 if j == 0 else 1)
                 dw = torch.zeros(Cout, k * Cin, device=dev, dtype=torch.float32)
-                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dycat, j * Cout), Ncat),
+                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dyop, j * Cout), Ncat),
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
-                     mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L))
+                     mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L),
+                     math=mth)
                 grads += [dw, bias_grad(j)]
         return (dx, None, dgam, dbet, None, *grads)
 

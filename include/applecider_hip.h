@@ -76,7 +76,11 @@ enum { AC_GEMM_NT = 0, AC_GEMM_NN = 1, AC_GEMM_TN = 2 };
 enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC_ACT_TANH = 4 };
 /* dact: derivative taken from aux.  GELU/RELU expect the PRE-activation in aux,
  * SIGMOID/TANH expect the activation OUTPUT in aux. */
-enum { AC_MATH_F32 = 0, AC_MATH_BF16 = 1 }; /* MFMA input type; storage is fp32 */
+/* MFMA input type.  F32 / BF16: operands are fp32 in memory (BF16 rounds them while staging).
+ * BF16_IN: A and B are already bf16 in memory (ac_cast_bf16 / ac_transpose_cast_bf16); strides,
+ * goff entries and inner extents are in bf16 elements and multiples of 8; modes NT and TN only.
+ * C, bias, aux, residual stay fp32 in every mode. */
+enum { AC_MATH_F32 = 0, AC_MATH_BF16 = 1, AC_MATH_BF16_IN = 2 };
 
 typedef struct ac_rowmap {
     int32_t r1, r2;
@@ -112,6 +116,11 @@ typedef struct ac_gemm_desc {
 } ac_gemm_desc;
 
 int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
+/* y = bf16(x) elementwise (round to nearest even); y is a uint16 buffer. */
+int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream);
+/* y[c, r] = bf16(x[r, c]) : the k-contiguous bf16 copy of an operand stored row-contiguous. */
+int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int64_t ldy, int64_t rows,
+                           int32_t cols, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row-wise LayerNorm over the last dimension (nn.LayerNorm: astrominn.py:25,34,47,52;

@@ -539,3 +539,95 @@ def test_optimizers(dev):
     tot = (g0 * 3).norm().item()
     assert abs(math.sqrt(ss.item()) - tot) < 1e-3 * tot
     assert abs(coef.item() - min(1.0, 1.0 / (tot + 1e-6))) < 1e-6
+
+
+# ----------------------------------------------------------------------------- bf16-operand path
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 136, 520), (128, 128, 16064), (304, 64, 96)])
+def test_gemm_bf16_operands(dev, M, N, K):
+    """NT and TN kernels that read bf16 operands (ds_read_b128 / ds_read_b64_tr_b16 fragments)
+    against an fp32 product of the same bf16-rounded inputs (exact up to summation order)."""
+    from applecider_amd import hipops as H
+    a, b = g(dev, M, K, seed=1), g(dev, N, K, seed=2)
+    ar, br = a.bfloat16().float(), b.bfloat16().float()
+    ref = ar @ br.t()
+    ad, bd = a.to(dev), b.to(dev)
+    a16, b16 = H.cast16(ad), H.cast16(bd)
+    assert torch.equal(a16.float().cpu(), ar)
+    c = torch.empty(M, N, device=dev)
+    H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a16), K), H.mat(H._p(b16), K), H.mat(H._p(c), N), math=2)
+    close(c, ref, tol=2e-5, name="bf16in NT")
+    # exact integers through the transposed-read path: C = A^T B with A [K, M], B [K, N]
+    at16, bt16 = H.cast16_T(ad), H.cast16_T(bd)  # [K, M], [K, N]
+    assert torch.equal(at16.float().cpu(), ar.t())
+    c2 = torch.empty(M, N, device=dev)
+    H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(at16), M), H.mat(H._p(bt16), N), H.mat(H._p(c2), N), math=2)
+    close(c2, ref, tol=2e-5, name="bf16in TN")
+    ai = (torch.arange(M * K).reshape(M, K).remainder(7).float() - 3)
+    bi = (torch.arange(N * K).reshape(N, K).remainder(5).float() - 2)
+    c3 = torch.zeros(M, N, device=dev)
+    ait, bit = H.cast16_T(ai.to(dev)), H.cast16_T(bi.to(dev))  # keep the operands alive
+    H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(ait), M), H.mat(H._p(bit), N), H.mat(H._p(c3), N),
+           math=2, accumulate=2, split_k=3)
+    assert torch.equal(c3.cpu(), ai @ bi.t())
+
+
+@pytest.fixture
+def bf16_mode():
+    from applecider_amd import hipops as H
+    H.set_math("bf16")
+    yield
+    H.set_math("f32")
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 1, 64, (3, 61, 1021)), (2, 128, 64, 128, (3, 31, 251)),
+                                             (4, 64, 256, 512, (3, 11, 31))])
+def test_conv_group1d_bf16(dev, bf16_mode, B, L, Cin, Cout, ks):
+    """bf16 matrix-core mode of the conv bank: same math as fp32 with operands rounded to bf16
+    (fp32 accumulate), so it is compared with torch on bf16-rounded x / w / dy at 3e-3."""
+    from applecider_amd import hipops as H
+    rb = lambda t: t.bfloat16().float()
+    x = rb(g(dev, B, Cin, L, seed=1)).requires_grad_(Cin != 1)
+    ws = [rb(g(dev, Cout, Cin, k, seed=10 + i) / math.sqrt(Cin * k)).requires_grad_() for i, k in enumerate(ks)]
+    bs = [g(dev, Cout, seed=20 + i).requires_grad_() for i in range(len(ks))]
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    go = rb(g(dev, *y.shape, seed=5))
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 1).contiguous().to(dev).requires_grad_(Cin != 1)
+    wd = [w.detach().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+    bd = [b.detach().to(dev).requires_grad_() for b in bs]
+    yd = H.conv_group1d(xd, ks, wd, bd)
+    yd.backward(go.permute(0, 2, 1).contiguous().to(dev))
+    close(yd.permute(0, 2, 1), y, tol=1e-4, name="y")
+    for i, k in enumerate(ks):
+        close(wd[i].grad.reshape(Cout, k, Cin).permute(0, 2, 1), ws[i].grad, tol=1e-4, name=f"dw{i}")
+    if Cin != 1:
+        close(xd.grad.permute(0, 2, 1), x.grad, tol=1e-4, name="dx")
+
+
+def test_linear_and_patchconv_bf16(dev, bf16_mode):
+    from applecider_amd import hipops as H
+    rb = lambda t: t.bfloat16().float()
+    x = rb(g(dev, 900, 384, seed=1)).requires_grad_()
+    w = rb(g(dev, 96, 384, seed=2) / 20).requires_grad_()
+    b = g(dev, 96, seed=3).requires_grad_()
+    y = F.linear(x, w, b)
+    go = rb(g(dev, *y.shape, seed=4))
+    y.backward(go)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+    yd = H.linear(xd, wd, bd)
+    yd.backward(go.to(dev))
+    close(yd, y, tol=1e-4), close(xd.grad, x.grad, tol=1e-4), close(wd.grad, w.grad, tol=1e-4)
+    close(bd.grad, b.grad, tol=1e-4)
+    B, H_, C, Co = 4, 7, 192, 384
+    x = rb(g(dev, B, C, H_, H_, seed=1)).requires_grad_()
+    w = rb(g(dev, Co, C, 2, 2, seed=2) / math.sqrt(4 * C)).requires_grad_()
+    y = F.conv2d(x, w, None, stride=2)
+    go = rb(g(dev, *y.shape, seed=4))
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_()
+    wd = w.detach().permute(0, 2, 3, 1).reshape(Co, 4 * C).contiguous().to(dev).requires_grad_()
+    yd = H.patch_conv2x2(xd, wd, None)
+    yd.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(yd.permute(0, 3, 1, 2), y, tol=1e-4, name="y")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, tol=1e-4, name="dx")
+    close(wd.grad.reshape(Co, 2, 2, C).permute(0, 3, 1, 2), w.grad, tol=1e-4, name="dw")

@@ -1,0 +1,54 @@
+"""Micro-benchmark of the gather-GEMM kernels (run on the GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import torch
+from applecider_amd import hipops as H
+dev = torch.device('cuda')
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+def plain(M, N, K, math):
+    a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev); c = torch.empty(M, N, device=dev)
+    if math == 2:
+        a16, b16 = H.cast16(a), H.cast16(b)
+        f = lambda: H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a16), K), H.mat(H._p(b16), K), H.mat(H._p(c), N), math=2)
+    else:
+        f = lambda: H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a), K), H.mat(H._p(b), K), H.mat(H._p(c), N), math=math)
+    ms = timeit(f)
+    print(f"plain NT M{M} N{N} K{K} math{math}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF")
+
+def conv(B, L, Cin, Cout, k, math):
+    P = k // 2; Lp = L + 2 * P
+    xpad = torch.randn(B, Lp, Cin, device=dev); w = torch.randn(Cout, k * Cin, device=dev); y = torch.empty(B, L, Cout, device=dev)
+    if math == 2:
+        x16, w16 = H.cast16(xpad), H.cast16(w)
+        f = lambda: H.gemm(H.AC_GEMM_NT, B * L, Cout, k * Cin, H.mat(H._p(x16), r1=L, r2=L, s1=Lp * Cin, s3=Cin), H.mat(H._p(w16), k * Cin), H.mat(H._p(y), Cout), math=2)
+    else:
+        f = lambda: H.gemm(H.AC_GEMM_NT, B * L, Cout, k * Cin, H.mat(H._p(xpad), r1=L, r2=L, s1=Lp * Cin, s3=Cin), H.mat(H._p(w), k * Cin), H.mat(H._p(y), Cout), math=math)
+    ms = timeit(f, 3)
+    print(f"conv fwd B{B} L{L} Cin{Cin} Cout{Cout} k{k} math{math}: {ms:.3f} ms  {2*B*L*Cout*k*Cin/ms/1e9:.1f} TF")
+
+def tn(M, N, K, math, split):
+    a = torch.randn(K, M, device=dev); b = torch.randn(K, N, device=dev); c = torch.zeros(M, N, device=dev)
+    if math == 2:
+        a16, b16 = H.cast16(a), H.cast16(b)
+        f = lambda: H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(a16), M), H.mat(H._p(b16), N), H.mat(H._p(c), N), math=2, accumulate=2, split_k=split)
+    else:
+        f = lambda: H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(a), M), H.mat(H._p(b), N), H.mat(H._p(c), N), math=math, accumulate=2, split_k=split)
+    ms = timeit(f, 3)
+    print(f"TN M{M} N{N} K{K} math{math} split{split}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF")
+
+for math in (0, 1, 2):
+    plain(8192, 8192, 4096, math)
+    plain(65536, 128, 4096, math)
+for math in (0, 2):
+    conv(512, 1024, 64, 128, 251, math)
+    conv(512, 256, 128, 256, 61, math)
+    tn(128, 16064, 524288, math, 8)
+    tn(4096, 4096, 8192, math, 1)
