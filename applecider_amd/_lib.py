@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("act", C.c_int32), ("dact", C.c_int32), ("accumulate", C.c_int32),
         ("split_k", C.c_int32), ("force_simple", C.c_int32),
-        ("alpha", C.c_float), ("_pad0", C.c_int32),
+        ("alpha", C.c_float), ("tile", C.c_int32),
         ("a", Mat), ("b", Mat), ("c", Mat),
         ("bias", C.c_void_p), ("pre_out", C.c_void_p), ("ld_pre", C.c_int64),
         ("aux", C.c_void_p), ("ld_aux", C.c_int64),

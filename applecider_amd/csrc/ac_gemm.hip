@@ -66,14 +66,14 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // epilogue: reg e of a 32x32 tile holds row (e&3)+8*(e>>2)+4*lh, col li.
 // Compile-time register indices keep the accumulators out of scratch.
-__device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (&acc)[2][2], int tm,
-                                           int tn, int wm, int wn, int li, int lh) {
-    const int n0 = tn * BN + wn * 64 + li, n1 = n0 + 32;
+__device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+                                           int row_base, int col_base, int li, int lh) {
+    const int n0 = col_base + li, n1 = n0 + 32;
     const int64_t c0 = inner_off(d.c.goff, n0 < d.N ? n0 : 0);
     const int64_t c1 = inner_off(d.c.goff, n1 < d.N ? n1 : 0);
     static_for<0, 32>([&](auto idx) {
         constexpr int sa = decltype(idx)::value / 16, e = decltype(idx)::value % 16;
-        const int m = tm * BM + wm * 64 + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = row_base + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m < d.M) {
             const int64_t crow = ac_rowaddr(d.c.rows, m);
             if (n0 < d.N) epilogue_store(d, m, n0, acc[sa][0][e], crow + c0);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    store_tile(d, acc, tm, tn, wm, wn, li, lh);
+    store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    store_tile(d, acc, tm, tn, wm, wn, li, lh);
+    store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -412,14 +412,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK16 = 64;
-constexpr int KC16_TILE = 128 * 64;   // ushort elements (16 KB)
-constexpr int RC16_PITCH = 160;       // ushort elements (320 B)
-constexpr int RC16_TILE = 64 * RC16_PITCH;  // 20 KB
 
+// ROWS x 64 bf16 image, NT threads: thread t owns rows (t>>3) + (NT/8)*i, 16-byte chunk t&7
+template <int ROWS, int NT>
 struct LoaderKC16 {
+    static constexpr int NCH = ROWS * 8 / NT;
     const unsigned short *ptr;
     const int32_t *goff;
-    int64_t base[4];
+    int64_t base[NCH];
     int inner_n, t;
     __device__ __forceinline__ void init(const ac_mat &m, int outer_n, int inner_extent, int origin,
                                          int tid) {
@@ -428,29 +428,29 @@ struct LoaderKC16 {
         inner_n = inner_extent;
         t = tid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = origin + (t >> 3) + 32 * i;
+        for (int i = 0; i < NCH; ++i) {
+            int r = origin + (t >> 3) + (NT / 8) * i;
             r = r < outer_n ? r : outer_n - 1;
             base[i] = ac_rowaddr(m.rows, r);
         }
     }
-    __device__ __forceinline__ void load(int kt, u32x4 (&v)[4]) const {
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) const {
         const int e = kt * BK16 + 8 * (t & 7);
         const bool kv = e < inner_n;
         const int64_t ko = goff ? (int64_t)goff[e >> 5] + (e & 31) : (int64_t)e;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             if (kv)
                 v[i] = *(const u32x4 *)(ptr + base[i] + ko);
             else
                 v[i] = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[4]) const {
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH]) const {
         const int c = t & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (t >> 3) + 32 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int r = (t >> 3) + (NT / 8) * i;
             *(u32x4 *)(tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = v[i];
         }
     }
@@ -461,7 +461,14 @@ __device__ __forceinline__ bf16x8 frag_kc16(const unsigned short *tile, int loca
     return *(const bf16x8 *)(tile + local * 64 + (chunk << 3));
 }
 
+// 64 x COLS bf16 image (row pitch COLS + 32): thread t owns k rows t/(COLS/8) + (NT*8/COLS)*i,
+// 16-byte chunk t % (COLS/8)
+template <int COLS, int NT>
 struct LoaderRC16 {
+    static constexpr int CPR = COLS / 8;          // chunks per k-row
+    static constexpr int KSTEP = NT / CPR;        // k rows covered per pass
+    static constexpr int NCH = 64 / KSTEP;
+    static constexpr int PITCH = COLS + 32;
     const unsigned short *ptr;
     ac_rowmap rows;
     int64_t io;
@@ -473,25 +480,25 @@ struct LoaderRC16 {
         rows = m.rows;
         outer_n = outer_extent;
         t = tid;
-        const int col = origin + 8 * (t & 15);
+        const int col = origin + 8 * (t % CPR);
         cv = col < inner_extent;
         io = cv ? (m.goff ? (int64_t)m.goff[col >> 5] + (col & 31) : (int64_t)col) : 0;
     }
-    __device__ __forceinline__ void load(int kt, u32x4 (&v)[4]) const {
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kg = kt * BK16 + (t >> 4) + 16 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int kg = kt * BK16 + t / CPR + KSTEP * i;
             if (cv && kg < outer_n)
                 v[i] = *(const u32x4 *)(ptr + ac_rowaddr(rows, kg) + io);
             else
                 v[i] = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[4]) const {
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = (t >> 4) + 16 * i;
-            *(u32x4 *)(tile + k * RC16_PITCH + 8 * (t & 15)) = v[i];
+        for (int i = 0; i < NCH; ++i) {
+            const int k = t / CPR + KSTEP * i;
+            *(u32x4 *)(tile + k * PITCH + 8 * (t % CPR)) = v[i];
         }
     }
 };
@@ -499,29 +506,42 @@ struct LoaderRC16 {
 // MFMA operand (8 consecutive k of column `local`) from an RC image via two transpose reads.
 // Lane l: 16-lane group g = l>>4 covers columns 16*(g&1).. and k half (g>>1) = l>>5; lane 4q+p of
 // the group addresses row q, columns 4p..4p+3 of the 4x16 block and receives column (l&15).
+// Row pitches of COLS+32 elements step 16 banks per k row: conflict free.
+template <int PITCH>
 __device__ __forceinline__ bf16x8 frag_rc16(const unsigned short *tile, int colbase, int s, int lane) {
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int k0 = 16 * s + 8 * (g >> 1);
-    const unsigned short *a0 = tile + (k0 + q) * RC16_PITCH + colbase + 16 * (g & 1) + 4 * pp;
+    const unsigned short *a0 = tile + (k0 + q) * PITCH + colbase + 16 * (g & 1) + 4 * pp;
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * RC16_PITCH));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * PITCH));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
 
-template <bool TN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
+// WM x WN waves, each owning a 64x64 output block: tile (64*WM) x (64*WN) x 64.
+template <bool TN, int WM, int WN>
+struct Bf16Cfg {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int TM = WM * 64, TNn = WN * 64;
+    static constexpr int A_TILE = TN ? 64 * (TM + 32) : TM * 64;   // ushort elements
+    static constexpr int B_TILE = TN ? 64 * (TNn + 32) : TNn * 64;
+    static constexpr int STAGE = A_TILE + B_TILE;
+    static constexpr int LDS_BYTES = 2 * STAGE * 2;
+};
+
+template <bool TN, int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16in_kernel(GemmParams p) {
+    using Cfg = Bf16Cfg<TN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm = reinterpret_cast<unsigned short *>(smem);
-    constexpr int TILE = TN ? RC16_TILE : KC16_TILE;
     const ac_gemm_desc &d = p.d;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -533,13 +553,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
     if (kt_end > p.nkt) kt_end = p.nkt;
     if (kt_begin >= kt_end) return;
 
-    typename std::conditional<TN, LoaderRC16, LoaderKC16>::type la, lb;
+    using LA = typename std::conditional<TN, LoaderRC16<Cfg::TM, Cfg::NT>, LoaderKC16<Cfg::TM, Cfg::NT>>::type;
+    using LB = typename std::conditional<TN, LoaderRC16<Cfg::TNn, Cfg::NT>, LoaderKC16<Cfg::TNn, Cfg::NT>>::type;
+    LA la;
+    LB lb;
     if (TN) {
-        la.init(d.a, d.K, d.M, tm * BM, t);
-        lb.init(d.b, d.K, d.N, tn * BN, t);
+        la.init(d.a, d.K, d.M, tm * Cfg::TM, t);
+        lb.init(d.b, d.K, d.N, tn * Cfg::TNn, t);
     } else {
-        la.init(d.a, d.M, d.K, tm * BM, t);
-        lb.init(d.b, d.N, d.K, tn * BN, t);
+        la.init(d.a, d.M, d.K, tm * Cfg::TM, t);
+        lb.init(d.b, d.N, d.K, tn * Cfg::TNn, t);
     }
 
     f32x16 acc[2][2];
@@ -550,11 +573,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u32x4 ra[4], rb[4];
+    u32x4 ra[LA::NCH], rb[LB::NCH];
     la.load(kt_begin, ra);
     lb.load(kt_begin, rb);
     la.store(sm, ra);
-    lb.store(sm + TILE, rb);
+    lb.store(sm + Cfg::A_TILE, rb);
     __syncthreads();
 
     int cur = 0;
@@ -564,15 +587,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
             la.load(kt + 1, ra);
             lb.load(kt + 1, rb);
         }
-        const unsigned short *at = sm + cur * 2 * TILE, *bt = at + TILE;
+        const unsigned short *at = sm + cur * Cfg::STAGE, *bt = at + Cfg::A_TILE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 a0, a1, b0, b1;
             if (TN) {
-                a0 = frag_rc16(at, wm * 64, s, lane);
-                a1 = frag_rc16(at, wm * 64 + 32, s, lane);
-                b0 = frag_rc16(bt, wn * 64, s, lane);
-                b1 = frag_rc16(bt, wn * 64 + 32, s, lane);
+                a0 = frag_rc16<Cfg::TM + 32>(at, wm * 64, s, lane);
+                a1 = frag_rc16<Cfg::TM + 32>(at, wm * 64 + 32, s, lane);
+                b0 = frag_rc16<Cfg::TNn + 32>(bt, wn * 64, s, lane);
+                b1 = frag_rc16<Cfg::TNn + 32>(bt, wn * 64 + 32, s, lane);
             } else {
                 a0 = frag_kc16(at, wm * 64 + li, s, lh);
                 a1 = frag_kc16(at, wm * 64 + 32 + li, s, lh);
@@ -585,13 +608,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16in_kernel(GemmParams p) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (more) {
-            la.store(sm + (cur ^ 1) * 2 * TILE, ra);
-            lb.store(sm + (cur ^ 1) * 2 * TILE + TILE, rb);
+            la.store(sm + (cur ^ 1) * Cfg::STAGE, ra);
+            lb.store(sm + (cur ^ 1) * Cfg::STAGE + Cfg::A_TILE, rb);
         }
         __syncthreads();
         cur ^= 1;
     }
-    store_tile(d, acc, tm, tn, wm, wn, li, lh);
+    store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
+}
+
+template <bool TN, int WM, int WN>
+int launch_bf16in(GemmParams &p, hipStream_t stream) {
+    using Cfg = Bf16Cfg<TN, WM, WN>;
+    const ac_gemm_desc &d = p.d;
+    p.tiles_m = (d.M + Cfg::TM - 1) / Cfg::TM;
+    p.tiles_n = (d.N + Cfg::TNn - 1) / Cfg::TNn;
+    p.nkt = (d.K + BK16 - 1) / BK16;
+    p.kt_per_split = (p.nkt + d.split_k - 1) / d.split_k;
+    static const hipError_t attr = hipFuncSetAttribute(
+        (const void *)gemm_bf16in_kernel<TN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        Cfg::LDS_BYTES);
+    if (attr != hipSuccess) return -(int)attr - 2000;
+    dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
+    hipLaunchKernelGGL((gemm_bf16in_kernel<TN, WM, WN>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
 }
 
 // fp32 -> bf16 (round to nearest even), 8 elements per thread
@@ -662,6 +703,23 @@ __global__ void gemm_simple_kernel(GemmParams p) {
     epilogue_store(d, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
 }
 
+// TN with tiny M x N and a long reduction (tower / router weight gradients: K = batch rows):
+// one wave per output element, lanes stride the reduction, shuffle-reduce.
+__global__ __launch_bounds__(256) void gemm_simple_tn_wave_kernel(GemmParams p) {
+    const ac_gemm_desc &d = p.d;
+    const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (widx >= (int64_t)d.M * d.N) return;
+    const int lane = threadIdx.x & 63;
+    const int m = (int)(widx / d.N), n = (int)(widx % d.N);
+    const float *A = (const float *)d.a.ptr, *B = (const float *)d.b.ptr;
+    const int64_t ai = inner_off(d.a.goff, m), bi = inner_off(d.b.goff, n);
+    float acc = 0.f;
+    for (int k = lane; k < d.K; k += 64)
+        acc = fmaf(A[ac_rowaddr(d.a.rows, k) + ai], B[ac_rowaddr(d.b.rows, k) + bi], acc);
+    acc = ac_wave_sum(acc);
+    if (lane == 0) epilogue_store(d, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
+}
+
 bool rowmap_aligned(const ac_rowmap &r) {
     return (r.s1 % 4 == 0) && (r.s2 % 4 == 0) && (r.s3 % 4 == 0);
 }
@@ -693,25 +751,15 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         p.d = d;
         if (d.split_k > 1) p.d.accumulate = 2;
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
-        p.tiles_m = (d.M + BM - 1) / BM;
-        p.tiles_n = (d.N + BN - 1) / BN;
-        p.nkt = (d.K + BK16 - 1) / BK16;
-        p.kt_per_split = (p.nkt + d.split_k - 1) / d.split_k;
-        dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
+        // tile shape: force_tile (tests/tuning) or by output shape
+        const int tile = d.tile;  // 0 auto, 1 = 128x128, 2 = 256x64, 3 = 256x128 (8 waves)
         if (d.mode == AC_GEMM_TN) {
-            // 80 KB of dynamic LDS (two double-buffered 20 KB images): above the 64 KB default
-            static const hipError_t attr = hipFuncSetAttribute(
-                (const void *)gemm_bf16in_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                4 * RC16_TILE * (int)sizeof(short));
-            if (attr != hipSuccess) return -(int)attr - 2000;
-            hipLaunchKernelGGL((gemm_bf16in_kernel<true>), grid, dim3(256),
-                               4 * RC16_TILE * sizeof(short), stream, p);
+            if (tile == 3) return launch_bf16in<true, 4, 2>(p, stream);
+            return launch_bf16in<true, 2, 2>(p, stream);
         }
-        else
-            hipLaunchKernelGGL((gemm_bf16in_kernel<false>), grid, dim3(256),
-                               4 * KC16_TILE * sizeof(short), stream, p);
-        AC_CHECK_LAUNCH();
-        return AC_OK;
+        if (tile == 2 || (tile == 0 && d.N <= 64 && d.M >= 256)) return launch_bf16in<false, 4, 1>(p, stream);
+        if (tile == 3) return launch_bf16in<false, 4, 2>(p, stream);
+        return launch_bf16in<false, 2, 2>(p, stream);
     }
     const bool a_kc = d.mode != AC_GEMM_TN;
     const bool b_kc = d.mode == AC_GEMM_NT;
@@ -730,6 +778,12 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         // and honours the caller's accumulate mode.
         p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = 0;
         int64_t total = (int64_t)d.M * d.N;
+        if (d.mode == AC_GEMM_TN && d.K >= 128 && total <= 65536) {
+            hipLaunchKernelGGL(gemm_simple_tn_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0,
+                               stream, p);
+            AC_CHECK_LAUNCH();
+            return AC_OK;
+        }
         int blocks = (int)((total + 255) / 256);
         hipLaunchKernelGGL(gemm_simple_kernel, dim3(blocks), dim3(256), 0, stream, p);
         AC_CHECK_LAUNCH();

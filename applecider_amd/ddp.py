@@ -40,8 +40,16 @@ class GradBuckets:
         self._build(bucket_bytes // 4)
         self._inv_world = None
         if self.world > 1:
+            self._index = {id(p): i for i, p in enumerate(self.fp.params)}
             for i, p in enumerate(self.fp.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            # gradients written straight into the flat buffer by the HIP backward kernels
+            # (hipops gradient sinks) bypass autograd's accumulation: get told about them too
+            try:
+                from . import hipops as H
+                H._grad_callbacks.append(self._on_sink)
+            except Exception:  # CPU-only unit tests without the shared library
+                pass
 
     def _build(self, bucket_elems: int):
         begin, n, cur = 0, 0, 0
@@ -80,6 +88,11 @@ class GradBuckets:
                 self._launch(b)
         return hook
 
+    def _on_sink(self, param):
+        i = self._index.get(id(param))
+        if i is not None:
+            self._make_hook(i)(param)
+
     def finish(self):
         """Call after backward(): completes the exchange and leaves the AVERAGED gradient in the
         flat buffer.  No host synchronisation on GPU (stream waits only)."""
@@ -104,6 +117,12 @@ class GradBuckets:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        try:
+            from . import hipops as H
+            if self._on_sink in H._grad_callbacks:
+                H._grad_callbacks.remove(self._on_sink)
+        except Exception:
+            pass
 
 
 def init_from_env(backend: Optional[str] = None):

@@ -65,12 +65,12 @@ def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) 
 
 def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
          ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
-         accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None):
+         accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0):
     d = GemmDesc()
     d.mode, d.math = mode, (_MATH if math is None else math)
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.act, d.dact, d.accumulate = act, dact, accumulate
-    d.split_k, d.force_simple, d.alpha = int(split_k), force_simple, alpha
+    d.split_k, d.force_simple, d.alpha, d.tile = int(split_k), force_simple, alpha, tile
     d.a, d.b, d.c = a, b, c
     d.bias = _p(bias)
     d.pre_out, d.ld_pre = _p(pre_out), ld_pre
@@ -98,6 +98,59 @@ def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib_().ac_transpose_cast_bf16(_p(t2d), Cc, _p(y), R, R, Cc, _stream()),
                "ac_transpose_cast_bf16")
     return y
+
+
+_step_cache: dict = {}
+
+
+def clear_step_cache():
+    """Drop cached bf16 copies of the weights (call whenever parameters change: optimizer step)."""
+    _step_cache.clear()
+
+
+def _cached(t: torch.Tensor, kind: str, fn):
+    key = (t.data_ptr(), t.numel(), t._version, kind)
+    v = _step_cache.get(key)
+    if v is None:
+        v = fn(t)
+        _step_cache[key] = v
+    return v
+
+
+def cast16_w(w):
+    """bf16 copy of a weight, computed once per optimizer step."""
+    return _cached(w, "c", cast16)
+
+
+def cast16_wT(w2d):
+    return _cached(w2d, "t", cast16_T)
+
+
+# Gradient sinks: when a parameter already owns a contiguous fp32 .grad (the flat gradient buffer of
+# applecider_amd.optim), backward kernels accumulate straight into it (atomics / C += v) instead of
+# materialising a temporary that autograd then adds — one pass less over every gradient.  Whoever
+# needs to know that a parameter's gradient is complete (ddp.GradBuckets) registers a callback.
+_grad_callbacks: list = []
+_SINKS = True
+
+
+def enable_grad_sinks(on: bool):
+    global _SINKS
+    _SINKS = bool(on)
+
+
+def _sink(p):
+    if not _SINKS or p is None or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
+def _grad_written(p):
+    for cb in _grad_callbacks:
+        cb(p)
 
 
 def _big(M, N, K) -> bool:
@@ -158,8 +211,9 @@ class _Linear(Function):
                                   or colscale is not None)
         pre = torch.empty_like(y) if save_pre else None
         ctx.b16 = bf16_operands() and K % 8 == 0 and N % 8 == 0 and _big(M, N, K)
+        x16 = None
         if ctx.b16:
-            x16, w16 = cast16(x2), cast16(w)
+            x16, w16 = cast16(x2), cast16_w(w)
             gemm(AC_GEMM_NT, M, N, K, mat(_p(x16), K), mat(_p(w16), K), mat(_p(y), N), bias=b,
                  act=act, pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
                  math=_lib.MATH_BF16_IN)
@@ -170,7 +224,8 @@ class _Linear(Function):
         ctx.shape_x = x.shape
         ctx.has_b = b is not None
         aux = pre if save_pre else (y if act != ACT_NONE else None)
-        ctx.save_for_backward(x2, w, aux, colscale)
+        ctx.save_for_backward(x16 if ctx.b16 else x2, w, aux, colscale)  # bf16 mode keeps the bf16 copy
+        ctx.wp, ctx.bp = w, b
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -196,23 +251,31 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             if ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
-                wT16 = cast16_T(w)
+                wT16 = cast16_wT(w)
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
                      math=_lib.MATH_BF16_IN)
             else:
                 gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
             dx = dx.reshape(ctx.shape_x)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
-            if ctx.b16:
-                x16 = cast16(x2)
-                gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(x16), K), mat(_p(dw), K),
+            wsink = _sink(ctx.wp)
+            dw = wsink if wsink is not None else torch.zeros(N, K, device=dy.device, dtype=torch.float32)
+            if ctx.b16:  # x2 is the bf16 copy saved by forward
+                gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M), math=_lib.MATH_BF16_IN)
             else:
                 gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M))
+            if wsink is not None:
+                dw = None
+                _grad_written(ctx.wp)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = colsum(_p(g), N, M, N, dy.device)
+            bsink = _sink(ctx.bp)
+            if bsink is not None:
+                _lib.check(_lib_().ac_colsum(_p(g), N, _p(bsink), M, N, 1, _stream()), "ac_colsum")
+                _grad_written(ctx.bp)
+            else:
+                db = colsum(_p(g), N, M, N, dy.device)
         dres = dy if ctx.has_res else None
         return dx, dw, db, None, dres, dcs
 
@@ -237,6 +300,7 @@ class _LayerNorm(Function):
                    "ac_layernorm_fwd")
         ctx.act = act
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.gp, ctx.bp = gamma, beta
         return y
 
     @staticmethod
@@ -246,11 +310,17 @@ class _LayerNorm(Function):
         Cn = x.shape[-1]
         rows = x.numel() // Cn
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(beta)
+        gs, bs = _sink(ctx.gp), _sink(ctx.bp)
+        both = gs is not None and bs is not None
+        dg = gs if both else torch.zeros_like(gamma)
+        db = bs if both else torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
                                             _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
                                             ctx.act, _stream()), "ac_layernorm_bwd")
+        if both:
+            _grad_written(ctx.gp)
+            _grad_written(ctx.bp)
+            return dx, None, None, None, None
         return dx, dg, db, None, None
 
 
@@ -496,6 +566,7 @@ class _DWConv7(Function):
                    "ac_dwconv7x7_fwd")
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.wp, ctx.bp = w, b
         return y
 
     @staticmethod
@@ -504,10 +575,17 @@ class _DWConv7(Function):
         dy = _chk(dy, "dy")
         B, H, W_, Cn = x.shape
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros(Cn, device=x.device, dtype=torch.float32)
+        ws, bs = _sink(ctx.wp), _sink(ctx.bp)
+        both = ws is not None and (bs is not None or not ctx.has_b)
+        dw = ws if both else torch.zeros_like(w)
+        db = bs if (both and ctx.has_b) else torch.zeros(Cn, device=x.device, dtype=torch.float32)
         _lib.check(_lib_().ac_dwconv7x7_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
                                             Cn, _stream()), "ac_dwconv7x7_bwd")
+        if both:
+            _grad_written(ctx.wp)
+            if ctx.has_b:
+                _grad_written(ctx.bp)
+            return dx, None, None
         return dx, dw, (db if ctx.has_b else None)
 
 
@@ -534,7 +612,7 @@ class _PatchConv2x2(Function):
         y = torch.empty(M, Cout, device=x.device, dtype=torch.float32)
         ctx.b16 = bf16_operands() and Cout % 8 == 0
         if ctx.b16:
-            x16, w16 = cast16(x), cast16(w)  # keep both alive until the launch is enqueued
+            x16, w16 = cast16(x), cast16_w(w)  # keep both alive until the launch is enqueued
             gemm(AC_GEMM_NT, M, Cout, 4 * Cn, mat(_p(x16), goff=goff, **amap),
                  mat(_p(w16), 4 * Cn), mat(_p(y), Cout), bias=b, math=_lib.MATH_BF16_IN)
         else:
@@ -542,6 +620,7 @@ class _PatchConv2x2(Function):
                  mat(_p(y), Cout), bias=b)
         ctx.save_for_backward(x, w, goff)
         ctx.amap, ctx.has_b = amap, b is not None
+        ctx.wp, ctx.bp = w, b
         return y.reshape(B, OH, OW, Cout)
 
     @staticmethod
@@ -557,14 +636,15 @@ class _PatchConv2x2(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.zeros_like(x)  # border pixels dropped by the stride get zero gradient
             if ctx.b16:
-                wT16 = cast16_T(w)
+                wT16 = cast16_wT(w)
                 gemm(AC_GEMM_NT, M, 4 * Cn, Cout, mat(_p(dy16), Cout), mat(_p(wT16), Cout),
                      mat(_p(dx), goff=goff, **ctx.amap), math=_lib.MATH_BF16_IN)
             else:
                 gemm(AC_GEMM_NN, M, 4 * Cn, Cout, mat(_p(dy2), Cout), mat(_p(w), 4 * Cn),
                      mat(_p(dx), goff=goff, **ctx.amap))
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            wsink = _sink(ctx.wp)
+            dw = wsink if wsink is not None else torch.zeros_like(w)
             if ctx.b16:
                 x16 = cast16(x)
                 gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy16), Cout),
@@ -573,8 +653,16 @@ class _PatchConv2x2(Function):
             else:
                 gemm(AC_GEMM_TN, Cout, 4 * Cn, M, mat(_p(dy2), Cout), mat(_p(x), goff=goff, **ctx.amap),
                      mat(_p(dw), 4 * Cn), accumulate=2, split_k=_split_for(Cout, 4 * Cn, M))
+            if wsink is not None:
+                dw = None
+                _grad_written(ctx.wp)
         if ctx.has_b:
-            db = colsum(_p(dy2), Cout, M, Cout, dy.device)
+            bsink = _sink(ctx.bp)
+            if bsink is not None:
+                _lib.check(_lib_().ac_colsum(_p(dy2), Cout, _p(bsink), M, Cout, 1, _stream()), "ac_colsum")
+                _grad_written(ctx.bp)
+            else:
+                db = colsum(_p(dy2), Cout, M, Cout, dy.device)
         return dx, dw, db
 
 
@@ -746,13 +834,14 @@ class _ConvGroup1d(Function):
                 xpad = cast16(xpad)
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
-                wop = cast16(ws[j]) if b16 else ws[j]
+                wop = cast16_w(ws[j]) if b16 else ws[j]
                 gemm(AC_GEMM_NT, B * L, Cout, k * Cin,
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(wop), k * Cin),
                      mat(_p(ycat, j * Cout), Ncat), bias=bs[j], math=mth)
             ctx.Lp = Lp
         ctx.fused_ln = ln_gamma is not None
+        ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
         if ctx.fused_ln:
             rows = B * L
             y = torch.empty_like(ycat)
@@ -780,7 +869,10 @@ class _ConvGroup1d(Function):
             xpad, ws = saved[0], list(saved[1:1 + nconv])
             ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:]
             dpre = torch.empty_like(ycat)
-            dgam, dbet = torch.zeros_like(ln_gamma), torch.zeros_like(ln_beta)
+            gsink, bsink = _sink(ctx.params[1]), _sink(ctx.params[2])
+            ln_direct = gsink is not None and bsink is not None
+            dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
+            dbet = bsink if ln_direct else torch.zeros_like(ln_beta)
             fuse_bias = Ncat % 4 == 0 and Ncat <= 1536
             bias_sums = torch.zeros(Ncat, device=dev, dtype=torch.float32) if fuse_bias else None
             _lib.check(_lib_().ac_layernorm_bwd(_p(dycat), Ncat, _p(ycat), Ncat, _p(mean), _p(rstd),
@@ -788,6 +880,10 @@ class _ConvGroup1d(Function):
                                                 _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
                                                 _stream()), "ac_layernorm_bwd")
             dycat = dpre
+            if ln_direct:
+                dgam = dbet = None
+                _grad_written(ctx.params[1])
+                _grad_written(ctx.params[2])
         else:
             xpad, *ws = ctx.saved_tensors
 
@@ -837,7 +933,7 @@ class _ConvGroup1d(Function):
                     if b16:
                         # NT against the k-contiguous copy of the taps: wT[(t,ci), co]; operand row ci,
                         # inner index (t, co) through an offset table
-                        wT = cast16_T(ws[j])  # [k*Cin, Cout]
+                        wT = cast16_wT(ws[j])  # [k*Cin, Cout]
                         goff_b = _table(("cg_dxw", Cin, Cout, k),
                                         lambda k=k: [t * Cin * Cout + cb * 32 for t in range(k)
                                                      for cb in range(Cout // 32)], dev)
@@ -850,11 +946,16 @@ class _ConvGroup1d(Function):
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
                              mat(_p(dx), Cin), accumulate=0 if j == 0 else 1)
-                dw = torch.zeros(Cout, k * Cin, device=dev, dtype=torch.float32)
+                wsink = _sink(ctx.params[0][j])
+                dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev,
+                                                                  dtype=torch.float32)
                 gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dyop, j * Cout), Ncat),
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L),
                      math=mth)
+                if wsink is not None:
+                    dw = None
+                    _grad_written(ctx.params[0][j])
                 grads += [dw, bias_grad(j)]
         return (dx, None, dgam, dbet, None, *grads)
 

@@ -135,6 +135,7 @@ class FlatAdam:
         H.adam_flat(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_count,
                     getattr(self, "_clip", None))
         self._clip = None
+        H.clear_step_cache()  # cached bf16 weight copies are stale now
 
     @property
     def flat_grad(self):
@@ -171,6 +172,7 @@ class FlatSGD:
         H.sgd_flat(self.fp.flat, self.fp.grad, self.buf, float(g["lr"]), float(g["momentum"]),
                    float(g["weight_decay"]), self.first)
         self.first = False
+        H.clear_step_cache()
 
     @property
     def flat_grad(self):

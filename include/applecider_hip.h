@@ -103,7 +103,7 @@ typedef struct ac_gemm_desc {
     int32_t split_k;      /* >= 1 */
     int32_t force_simple; /* 1: use the scalar reference kernel (tests) */
     float alpha;
-    int32_t _pad0;
+    int32_t tile;         /* BF16_IN only: 0 auto, 1 = 128x128, 2 = 256x64, 3 = 256x128 tile */
     ac_mat a, b, c;
     const float *bias;
     float *pre_out;

@@ -44,11 +44,33 @@ def tn(M, N, K, math, split):
     ms = timeit(f, 3)
     print(f"TN M{M} N{N} K{K} math{math} split{split}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF")
 
-for math in (0, 1, 2):
-    plain(8192, 8192, 4096, math)
-    plain(65536, 128, 4096, math)
-for math in (0, 2):
-    conv(512, 1024, 64, 128, 251, math)
-    conv(512, 256, 128, 256, 61, math)
-    tn(128, 16064, 524288, math, 8)
-    tn(4096, 4096, 8192, math, 1)
+
+def conv_t(B, L, Cin, Cout, k, tile):
+    P = k // 2; Lp = L + 2 * P
+    xpad = torch.randn(B, Lp, Cin, device=dev); w = torch.randn(Cout, k * Cin, device=dev); y = torch.empty(B, L, Cout, device=dev)
+    x16, w16 = H.cast16(xpad), H.cast16(w)
+    f = lambda: H.gemm(H.AC_GEMM_NT, B * L, Cout, k * Cin, H.mat(H._p(x16), r1=L, r2=L, s1=Lp * Cin, s3=Cin), H.mat(H._p(w16), k * Cin), H.mat(H._p(y), Cout), math=2, tile=tile)
+    ms = timeit(f, 3)
+    print(f"conv fwd B{B} L{L} Cin{Cin} Cout{Cout} k{k} tile{tile}: {ms:.3f} ms  {2*B*L*Cout*k*Cin/ms/1e9:.1f} TF")
+
+def plain_t(M, N, K, tile, mode="NT", split=1):
+    c = torch.zeros(M, N, device=dev)
+    if mode == "NT":
+        a16, b16 = H.cast16(torch.randn(M, K, device=dev)), H.cast16(torch.randn(N, K, device=dev))
+        f = lambda: H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a16), K), H.mat(H._p(b16), K), H.mat(H._p(c), N), math=2, tile=tile)
+    else:
+        a16, b16 = H.cast16(torch.randn(K, M, device=dev)), H.cast16(torch.randn(K, N, device=dev))
+        f = lambda: H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(a16), M), H.mat(H._p(b16), N), H.mat(H._p(c), N), math=2, tile=tile, accumulate=2, split_k=split)
+    ms = timeit(f, 3)
+    print(f"{mode} M{M} N{N} K{K} tile{tile} split{split}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF")
+
+for tile in (1, 3):
+    plain_t(8192, 8192, 4096, tile)
+    conv_t(512, 1024, 64, 128, 251, tile)
+    conv_t(512, 256, 128, 256, 61, tile)
+    plain_t(4096, 4096, 8192, tile, "TN")
+    plain_t(128, 16064, 524288, tile, "TN", 8)
+    plain_t(512, 1032, 262144, tile, "TN", 16)
+for tile in (1, 2):
+    plain_t(524288, 64, 32128, tile)       # stage-2 dX shape
+    plain_t(131072, 64, 4096, tile)
