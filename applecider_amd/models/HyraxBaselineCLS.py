@@ -101,3 +101,39 @@ class HyraxBaselineCLS(nn.Module):
             return (photo_tensor, data["pad_mask"], label_tensor)
         false_mask = np.zeros((photo_tensor.shape[0], photo_tensor.shape[1] + 1), dtype=bool)
         return (photo_tensor, false_mask, label_tensor)
+
+
+@hyrax_model
+class MPTModel(nn.Module):
+    """Masked-pretraining model (HyraxBaselineCLS.py:194-364): same encoder stack plus flux / band /
+    dt heads.  Constructor, `forward(z)` (the three heads), `to_tensor` and the state_dict follow the
+    reference; the masked pre-training `train_step` (per-band random masking + the three-term product
+    loss, :226-284) is the next row of SURVEY §8f and is not on the MI355X path yet."""
+
+    def __init__(self, config, data_sample=None):
+        super().__init__()
+        self.config = config
+        mc = config["model"]["HyraxBaselineCLS"]
+        d = mc["d_model"]
+        self.encoder = Encoder(d, mc["n_heads"], d * 4, mc["dropout"], mc["n_layers"])
+        self.in_proj = InProj8(7, d)
+        self.cls_tok = nn.Parameter(torch.zeros(1, 1, d))
+        self.time2vec = Time2Vec(d)
+        self.head_flux = Linear(d, 1)
+        self.head_band = Linear(d, 3)
+        self.head_dt = Linear(d, 1)
+        self.optimizer = FlatAdam([{"params": list(self.parameters())}], lr=1e-4, weight_decay=1e-2,
+                                  decoupled=True)  # torch.optim.AdamW(lr=1e-4) defaults
+
+    def forward(self, z):
+        return self.head_flux(z), self.head_band(z), self.head_dt(z)
+
+    def encode(self, data, pad):
+        h = embed_tokens(self.in_proj, self.time2vec, self.cls_tok, data)
+        return self.encoder(h, extend_pad_mask(pad))
+
+    def train_step(self, batch):
+        raise NotImplementedError("MPTModel.train_step (masked pre-training) is not built on the "
+                                  "MI355X path yet; see DESIGN.md section 7")
+
+    to_tensor = staticmethod(HyraxBaselineCLS.to_tensor)
