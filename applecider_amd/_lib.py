@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
 
 AC_GEMM_NT, AC_GEMM_NN, AC_GEMM_TN = 0, 1, 2
+AC_EINVAL = -22
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 MATH_F32, MATH_BF16, MATH_BF16_IN = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU,
@@ -43,6 +44,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ConvWinDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("a_batch_stride", C.c_int64), ("a_row_stride", C.c_int64),
+                ("a_col_off", C.c_int32), ("row_base", C.c_int32),
+                ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
+                ("w", C.c_void_p), ("w_row_stride", C.c_int64), ("w_tap_stride", C.c_int64),
+                ("flip", C.c_int32), ("N", C.c_int32), ("c", C.c_void_p), ("ldc", C.c_int64),
+                ("bias", C.c_void_p), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
 class AdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -56,6 +66,7 @@ SIGNATURES = {
     "ac_abi_version": [],
     "ac_strerror": [_I32],
     "ac_gemm": [C.POINTER(GemmDesc), _P],
+    "ac_conv1d_window_bf16": [C.POINTER(ConvWinDesc), _P],
     "ac_cast_bf16": [_P, _P, _I64, _P],
     "ac_transpose_cast_bf16": [_P, _I64, _P, _I64, _I64, _I32, _P],
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P],

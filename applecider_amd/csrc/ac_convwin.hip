@@ -1,0 +1,209 @@
+// LDS-resident-window Conv1d on the bf16 matrix cores (gfx950).
+//
+// The generic gather-GEMM treats a 'same' Conv1d as an implicit GEMM whose A rows are overlapping
+// windows of the padded sequence, so each input element is re-read k times through L1/L2 (and from
+// MALL/HBM once the per-workgroup window outgrows L1: the stage-2 input-gradient product streamed
+// 33 GB that way).  Here a workgroup loads its whole input window
+//        rows [l0, l0 + BM + k - 1)  x  C channels   (bf16, up to 130 KB of the 160 KB LDS)
+// ONCE, and the K loop (taps x channel tiles) reads the A fragments straight from that window at a
+// row offset of one row per tap; only the weights stream (global -> registers -> double-buffered
+// LDS, one barrier per 64-deep K tile).  Used for the forward product (A = padded input) and the
+// input-gradient product (A = padded output gradient, taps flipped) of SpectraNetBlock
+// (src/applecider/models/spectranet.py:18-20,25) when L is a multiple of the row tile.
+#include "ac_common.h"
+#include <hip/hip_bf16.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvWinParams {
+    ac_convwin_desc d;
+    int tiles_l, tiles_n, cchunks;  // cchunks = C / 8 (16-byte chunks per window row)
+};
+
+// window image: row r, 16-byte chunk cc -> element offset.  128-byte rows (C = 64) alternate the
+// two halves of the 256-byte bank row, wider rows start on a bank-row boundary.
+template <int C>
+__device__ __forceinline__ int win_off(int r, int cc) {
+    if (C == 64) return r * 64 + ((cc ^ ((r >> 1) & 7)) << 3);
+    return r * C + (((cc & ~15) | ((cc & 15) ^ (r & 15))) << 3);
+}
+
+template <int WM, int WN, int C>
+__global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinParams p) {
+    constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64;
+    constexpr int BCH = BN * 8 / NT;  // weight chunks per thread per K tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short *win = reinterpret_cast<unsigned short *>(smem);
+    const ac_convwin_desc &d = p.d;
+    const int W = BM + d.k - 1;
+    unsigned short *bst = win + W * C;  // two weight stages of BN*64 elements
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // tile order: n fastest, then l tiles, then batch (blocks of one XCD share a weight panel)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tn = wg % p.tiles_n;
+    const int tl = (wg / p.tiles_n) % p.tiles_l;
+    const int b = wg / (p.tiles_n * p.tiles_l);
+    const int l0 = tl * BM;
+
+    // ---- window: global -> LDS, once
+    {
+        const unsigned short *a = (const unsigned short *)d.a + (int64_t)b * d.a_batch_stride +
+                                  (int64_t)(d.row_base + l0) * d.a_row_stride + d.a_col_off;
+        const int total = W * (C / 8);
+        for (int idx = t; idx < total; idx += NT) {
+            const int r = idx / (C / 8), cc = idx % (C / 8);
+            const u32x4 v = *(const u32x4 *)(a + (int64_t)r * d.a_row_stride + cc * 8);
+            *(u32x4 *)(win + win_off<C>(r, cc)) = v;
+        }
+    }
+
+    // ---- weight loader: BN rows x 64 k per K tile, thread -> rows (t>>3) + (NT/8)*i, chunk t&7
+    const unsigned short *wptr = (const unsigned short *)d.w;
+    int64_t wbase[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        int n = tn * BN + (t >> 3) + (NT / 8) * i;
+        n = n < d.N ? n : d.N - 1;
+        wbase[i] = (int64_t)n * d.w_row_stride + 8 * (t & 7);
+    }
+    const int ctiles = C / 64;
+    const int nkt = d.k * ctiles;
+    auto koff = [&](int kt) -> int64_t {
+        const int tap = kt / ctiles, c0 = (kt % ctiles) * 64;
+        return (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + c0;
+    };
+    auto wload = [&](int kt, u32x4 (&v)[BCH]) {
+        const int64_t ko = koff(kt);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) v[i] = *(const u32x4 *)(wptr + wbase[i] + ko);
+    };
+    auto wstore = [&](unsigned short *tile, const u32x4 (&v)[BCH]) {
+        const int c = t & 7;
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int r = (t >> 3) + (NT / 8) * i;
+            *(u32x4 *)(tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = v[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u32x4 rb[BCH];
+    wload(0, rb);
+    wstore(bst, rb);
+    __syncthreads();  // window + first weight tile visible
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) wload(kt + 1, rb);
+        const int tap = kt / ctiles, cc0 = (kt % ctiles) * 8;
+        const unsigned short *bt = bst + cur * (BN * 64);
+        const int r0 = wm * 64 + li + tap, r1 = r0 + 32;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cc = cc0 + 2 * s + lh;
+            const bf16x8 a0 = *(const bf16x8 *)(win + win_off<C>(r0, cc));
+            const bf16x8 a1 = *(const bf16x8 *)(win + win_off<C>(r1, cc));
+            const int n0 = wn * 64 + li, n1 = n0 + 32;
+            const int chunk = 2 * s + lh;
+            const bf16x8 b0 = *(const bf16x8 *)(bt + n0 * 64 + ((chunk ^ ((n0 >> 1) & 7)) << 3));
+            const bf16x8 b1 = *(const bf16x8 *)(bt + n1 * 64 + ((chunk ^ ((n1 >> 1) & 7)) << 3));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) wstore(bst + (cur ^ 1) * (BN * 64), rb);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: out[b, l0 + m, n] (+)= acc (+ bias)
+    float *cb = d.c + ((int64_t)b * d.L + l0) * d.ldc;
+    const int nn0 = tn * BN + wn * 64 + li, nn1 = nn0 + 32;
+    const float bias0 = (d.bias && nn0 < d.N) ? d.bias[nn0] : 0.f;
+    const float bias1 = (d.bias && nn1 < d.N) ? d.bias[nn1] : 0.f;
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = wm * 64 + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float *row = cb + (int64_t)m * d.ldc;
+            const float v0 = acc[sa][0][e] + bias0, v1 = acc[sa][1][e] + bias1;
+            if (nn0 < d.N) row[nn0] = d.accumulate ? row[nn0] + v0 : v0;
+            if (nn1 < d.N) row[nn1] = d.accumulate ? row[nn1] + v1 : v1;
+        }
+    }
+}
+
+template <int WM, int WN, int C>
+int launch(ConvWinParams &p, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+    const ac_convwin_desc &d = p.d;
+    const size_t lds = ((size_t)(BM + d.k - 1) * C + 2 * BN * 64) * sizeof(short);
+    if (lds > 160 * 1024) return AC_EINVAL;
+    p.tiles_l = d.L / BM;
+    p.tiles_n = (d.N + BN - 1) / BN;
+    p.cchunks = C / 8;
+    static size_t configured = 0;  // grow-only attribute (benign race: same value from any thread)
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_kernel<WM, WN, C>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = 160 * 1024;
+    }
+    dim3 grid(d.B * p.tiles_l * p.tiles_n);
+    hipLaunchKernelGGL((conv1d_window_kernel<WM, WN, C>), grid, dim3(NT), lds, stream, p);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+template <int C>
+int dispatch(ConvWinParams &p, hipStream_t stream) {
+    const ac_convwin_desc &d = p.d;
+    const size_t win256 = (size_t)(256 + d.k - 1) * C * 2;
+    const bool wide = d.N > 64;
+    if (d.L % 256 == 0 && win256 + 2 * (wide ? 128 : 64) * 64 * 2 <= 160 * 1024)
+        return wide ? launch<4, 2, C>(p, stream) : launch<4, 1, C>(p, stream);
+    if (d.L % 128 == 0) return wide ? launch<2, 2, C>(p, stream) : launch<2, 1, C>(p, stream);
+    return AC_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int ac_conv1d_window_bf16(const ac_convwin_desc *dp, ac_stream_t stream_) {
+    if (!dp) return AC_EINVAL;
+    ConvWinParams p;
+    p.d = *dp;
+    const ac_convwin_desc &d = p.d;
+    if (!d.a || !d.w || !d.c || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.N <= 0) return AC_EINVAL;
+    if (!ac_aligned16(d.a) || !ac_aligned16(d.w)) return AC_EALIGN;
+    if ((d.a_row_stride % 8) || (d.a_batch_stride % 8) || (d.a_col_off % 8) || (d.w_row_stride % 8) ||
+        (d.w_tap_stride % 8))
+        return AC_EALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (d.C) {
+        case 64: return dispatch<64>(p, stream);
+        case 128: return dispatch<128>(p, stream);
+        case 256: return dispatch<256>(p, stream);
+        default: return AC_EINVAL;
+    }
+}

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -109,11 +110,16 @@ def clear_step_cache():
 
 
 def _cached(t: torch.Tensor, kind: str, fn):
-    key = (t.data_ptr(), t.numel(), t._version, kind)
-    v = _step_cache.get(key)
-    if v is None:
-        v = fn(t)
-        _step_cache[key] = v
+    # Only long-lived Parameters are cached, and an entry is valid only for the very same tensor
+    # object at the same version: a freed temporary's address can be handed to another tensor.
+    if not isinstance(t, torch.nn.Parameter):
+        return fn(t)
+    key = (id(t), kind)
+    hit = _step_cache.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
+        return hit[3]
+    v = fn(t)
+    _step_cache[key] = (weakref.ref(t), t._version, t.data_ptr(), v)
     return v
 
 
@@ -155,6 +161,34 @@ def _grad_written(p):
 
 def _big(M, N, K) -> bool:
     return float(M) * N * K >= 262144.0
+
+
+_CONVWIN = True
+
+
+def enable_conv_window(on: bool):
+    global _CONVWIN
+    _CONVWIN = bool(on)
+
+
+def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w16, w_row_stride,
+                w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate) -> bool:
+    """LDS-resident-window conv1d (ac_conv1d_window_bf16).  Returns False when the shape is not
+    covered (the caller then uses the generic gather-GEMM)."""
+    if not _CONVWIN or Cw not in (64, 128, 256) or L % 128:
+        return False
+    d = _lib.ConvWinDesc()
+    d.a, d.a_batch_stride, d.a_row_stride = _p(a16), a_batch_stride, a_row_stride
+    d.a_col_off, d.row_base = a_col_off, row_base
+    d.B, d.L, d.C, d.k = B, L, Cw, k
+    d.w, d.w_row_stride, d.w_tap_stride = _p(w16), w_row_stride, w_tap_stride
+    d.flip, d.N, d.c, d.ldc = int(flip), N, c_ptr, ldc
+    d.bias, d.accumulate = _p(bias), int(accumulate)
+    rc = _lib_().ac_conv1d_window_bf16(C.byref(d), _stream())
+    if rc == _lib.AC_EINVAL:
+        return False
+    _lib.check(rc, "ac_conv1d_window_bf16")
+    return True
 
 
 def _split_for(m_out: int, n_out: int, k_red: int) -> int:
@@ -251,7 +285,7 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             if ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
-                wT16 = cast16_wT(w)
+                wT16 = cast16_wT(ctx.wp if ctx.wp.shape == w.shape else w)
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
                      math=_lib.MATH_BF16_IN)
             else:
@@ -636,7 +670,7 @@ class _PatchConv2x2(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.zeros_like(x)  # border pixels dropped by the stride get zero gradient
             if ctx.b16:
-                wT16 = cast16_wT(w)
+                wT16 = cast16_wT(ctx.wp)
                 gemm(AC_GEMM_NT, M, 4 * Cn, Cout, mat(_p(dy16), Cout), mat(_p(wT16), Cout),
                      mat(_p(dx), goff=goff, **ctx.amap), math=_lib.MATH_BF16_IN)
             else:
@@ -835,6 +869,9 @@ class _ConvGroup1d(Function):
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 wop = cast16_w(ws[j]) if b16 else ws[j]
+                if b16 and conv_window(xpad, Lp * Cin, Cin, 0, off, B, L, Cin, k, wop, k * Cin, Cin,
+                                       False, Cout, _p(ycat, j * Cout), Ncat, bs[j], False):
+                    continue
                 gemm(AC_GEMM_NT, B * L, Cout, k * Cin,
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(wop), k * Cin),
@@ -933,7 +970,11 @@ class _ConvGroup1d(Function):
                     if b16:
                         # NT against the k-contiguous copy of the taps: wT[(t,ci), co]; operand row ci,
                         # inner index (t, co) through an offset table
-                        wT = cast16_wT(ws[j])  # [k*Cin, Cout]
+                        wT = cast16_wT(ctx.params[0][j])  # [k*Cin, Cout]
+                        if conv_window(dypad, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, wT, Cout,
+                                       Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):
+                            wT = None
+                    if b16 and wT is not None:
                         goff_b = _table(("cg_dxw", Cin, Cout, k),
                                         lambda k=k: [t * Cin * Cout + cb * 32 for t in range(k)
                                                      for cb in range(Cout // 32)], dev)
@@ -941,7 +982,7 @@ class _ConvGroup1d(Function):
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(wT), Cout, goff=goff_b), mat(_p(dx), Cin),
                              accumulate=0 if j == 0 else 1, math=mth)
-                    else:
+                    elif not b16:
                         gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),

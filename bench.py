@@ -62,6 +62,21 @@ class KernelTimer:
                 self.records.setdefault(names[mode], []).append((s, e, 2.0 * M * N * K))
         H.gemm = timed
 
+    def wrap_conv_window(self, H):
+        orig = H.conv_window
+
+        def timed(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+            if not self.enabled:
+                return orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ok = orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+            e.record()
+            if ok:
+                self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw))
+            return ok
+        H.conv_window = timed
+
     def wrap_dwconv(self, H):
         lib = H._lib_()
         orig = lib.ac_dwconv7x7_fwd
@@ -136,6 +151,7 @@ def main():
 
     timer = KernelTimer()
     timer.wrap_gemm(H)
+    timer.wrap_conv_window(H)
     timer.wrap_dwconv(H)
 
     for _ in range(args.warmup):
@@ -167,14 +183,15 @@ def main():
         return
 
     ks = timer.summary()
-    gemms = {k: v for k, v in ks.items() if k.startswith("gemm")}
+    gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d")}
     dom_name = max(gemms, key=lambda k: gemms[k]["ms"])
     dom = gemms[dom_name]
     achieved = dom["work"] / (dom["ms"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.math]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": f"{dom_name} ({'gemm_bf16_kernel' if args.math == 'bf16' else 'gemm_f32_kernel'})",
+                "kernel": ("conv1d_window_kernel" if dom_name.startswith("conv1d") else
+                           f"{dom_name} ({'gemm_bf16in_kernel' if args.math == 'bf16' else 'gemm_f32_kernel'})"),
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "all_gemm": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                  "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}

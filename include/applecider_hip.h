@@ -123,6 +123,33 @@ int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int64_t ldy, in
                            int32_t cols, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Conv1d with an LDS-resident input window (bf16 operands, fp32 output) — the fast path of the
+ * SpectraNetBlock conv bank (spectranet.py:18-20,25) for both the forward product and the
+ * input-gradient product:
+ *   out[b, l, n] (+)= bias[n] + sum_{t<k} sum_{c<C} A[b, row_base + l + t, a_col_off + c]
+ *                                                  * W[n, tap(t), c],   tap(t) = flip ? k-1-t : t
+ * A: bf16, element (b, row, col) at a + b*a_batch_stride + row*a_row_stride + col (zero-padded rows).
+ * W: bf16, element (n, tap, c) at w + n*w_row_stride + tap*w_tap_stride + c.
+ * Requirements: C in {64,128,256}; L % 128 == 0; strides/offsets multiples of 8 elements;
+ * (tile_rows + k - 1)*C*2 B + weight stages <= 160 KB (else AC_EINVAL: use ac_gemm).
+ * ---------------------------------------------------------------------- */
+typedef struct ac_convwin_desc {
+    const void *a;
+    int64_t a_batch_stride, a_row_stride;
+    int32_t a_col_off, row_base;
+    int32_t B, L, C, k;
+    const void *w;
+    int64_t w_row_stride, w_tap_stride;
+    int32_t flip, N;
+    float *c;
+    int64_t ldc;
+    const float *bias;
+    int32_t accumulate; /* 0 store, 1 out += */
+    int32_t _pad;
+} ac_convwin_desc;
+int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Row-wise LayerNorm over the last dimension (nn.LayerNorm: astrominn.py:25,34,47,52;
  * spectranet.py:21,31; HyraxBaselineCLS.py:34 and the two norms inside each
  * nn.TransformerEncoderLayer; timm ConvNeXt block norm / LayerNorm2d in NHWC).

@@ -580,11 +580,17 @@ def bf16_mode():
 
 
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 1, 64, (3, 61, 1021)), (2, 128, 64, 128, (3, 31, 251)),
-                                             (4, 64, 256, 512, (3, 11, 31))])
-def test_conv_group1d_bf16(dev, bf16_mode, B, L, Cin, Cout, ks):
+                                             (4, 64, 256, 512, (3, 11, 31)), (3, 512, 64, 128, (3, 31, 251)),
+                                             (2, 256, 128, 256, (3, 15, 61)), (2, 128, 64, 64, (5, 9, 33)),
+                                             (1, 256, 256, 256, (3, 11, 31))])
+@pytest.mark.parametrize("window", [True, False])
+def test_conv_group1d_bf16(dev, bf16_mode, B, L, Cin, Cout, ks, window):
     """bf16 matrix-core mode of the conv bank: same math as fp32 with operands rounded to bf16
     (fp32 accumulate), so it is compared with torch on bf16-rounded x / w / dy at 3e-3."""
     from applecider_amd import hipops as H
+    if window and (Cin == 1 or L % 128):
+        pytest.skip("LDS-window kernel does not cover this shape")
+    H.enable_conv_window(window)
     rb = lambda t: t.bfloat16().float()
     x = rb(g(dev, B, Cin, L, seed=1)).requires_grad_(Cin != 1)
     ws = [rb(g(dev, Cout, Cin, k, seed=10 + i) / math.sqrt(Cin * k)).requires_grad_() for i, k in enumerate(ks)]
@@ -595,8 +601,11 @@ def test_conv_group1d_bf16(dev, bf16_mode, B, L, Cin, Cout, ks):
     xd = x.detach().permute(0, 2, 1).contiguous().to(dev).requires_grad_(Cin != 1)
     wd = [w.detach().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
     bd = [b.detach().to(dev).requires_grad_() for b in bs]
-    yd = H.conv_group1d(xd, ks, wd, bd)
-    yd.backward(go.permute(0, 2, 1).contiguous().to(dev))
+    try:
+        yd = H.conv_group1d(xd, ks, wd, bd)
+        yd.backward(go.permute(0, 2, 1).contiguous().to(dev))
+    finally:
+        H.enable_conv_window(True)
     close(yd.permute(0, 2, 1), y, tol=1e-4, name="y")
     for i, k in enumerate(ks):
         close(wd[i].grad.reshape(Cout, k, Cin).permute(0, 2, 1), ws[i].grad, tol=1e-4, name=f"dw{i}")

@@ -64,13 +64,22 @@ def plain_t(M, N, K, tile, mode="NT", split=1):
     ms = timeit(f, 3)
     print(f"{mode} M{M} N{N} K{K} tile{tile} split{split}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF")
 
-for tile in (1, 3):
-    plain_t(8192, 8192, 4096, tile)
-    conv_t(512, 1024, 64, 128, 251, tile)
-    conv_t(512, 256, 128, 256, 61, tile)
-    plain_t(4096, 4096, 8192, tile, "TN")
-    plain_t(128, 16064, 524288, tile, "TN", 8)
-    plain_t(512, 1032, 262144, tile, "TN", 16)
-for tile in (1, 2):
-    plain_t(524288, 64, 32128, tile)       # stage-2 dX shape
-    plain_t(131072, 64, 4096, tile)
+
+def win(B, L, C, N, k, flip):
+    P = k // 2; Lp = L + 2 * P
+    a = H.cast16(torch.randn(B, Lp, C, device=dev)); w = H.cast16(torch.randn(N, k * C, device=dev)); y = torch.empty(B, L, N, device=dev)
+    for on in (True, False):
+        if on:
+            f = lambda: H.conv_window(a, Lp * C, C, 0, 0, B, L, C, k, w, k * C, C, flip, N, H._p(y), N, None, False)
+            assert f()
+        else:
+            f = lambda: H.gemm(H.AC_GEMM_NT, B * L, N, k * C, H.mat(H._p(a), r1=L, r2=L, s1=Lp * C, s3=C), H.mat(H._p(w), k * C), H.mat(H._p(y), N), math=2)
+        ms = timeit(f, 3)
+        print(f"{'window' if on else 'generic'} B{B} L{L} C{C} N{N} k{k}: {ms:.3f} ms  {2*B*L*N*k*C/ms/1e9:.1f} TF")
+
+win(512, 1024, 64, 128, 251, False)   # stage-2 fwd
+win(512, 1024, 128, 64, 251, False)   # stage-2 dX shape (A contiguous here)
+win(512, 256, 128, 256, 61, False)    # stage-3 fwd
+win(512, 256, 256, 128, 61, False)    # stage-3 dX shape
+win(512, 1024, 64, 128, 31, False)
+win(512, 1024, 64, 128, 3, False)
