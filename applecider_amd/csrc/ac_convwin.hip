@@ -23,6 +23,7 @@ namespace {
 struct ConvWinParams {
     ac_convwin_desc d;
     int tiles_l, tiles_n, cchunks;  // cchunks = C / 8 (16-byte chunks per window row)
+    int vec_epi;
 };
 
 // window image: row r, 16-byte chunk cc -> element offset.  128-byte rows (C = 64) alternate the
@@ -136,8 +137,37 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
         cur ^= 1;
     }
 
-    // ---- epilogue: out[b, l0 + m, n] (+)= acc (+ bias)
+    // ---- epilogue: out[b, l0 + m, n] (+)= acc (+ bias).  The wave parks each 32x64 half of its
+    // tile in 8 KB of the (now idle) window and re-reads it row-major: float4 stores.
     float *cb = d.c + ((int64_t)b * d.L + l0) * d.ldc;
+    if (p.vec_epi) {
+        float *wbuf = smem + wave * 2048;
+        const int rsub = lane >> 4, c4 = 4 * (lane & 15);
+        const int n = tn * BN + wn * 64 + c4;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias && n < d.N) bias4 = *(const f32x4 *)(d.bias + n);
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                wbuf[r * 64 + li] = acc[sa][0][e];
+                wbuf[r * 64 + 32 + li] = acc[sa][1][e];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + rsub;
+                f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
+                if (n < d.N) {
+                    f32x4 *dst = (f32x4 *)(cb + (int64_t)(wm * 64 + sa * 32 + r) * d.ldc + n);
+                    if (d.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+        return;
+    }
     const int nn0 = tn * BN + wn * 64 + li, nn1 = nn0 + 32;
     const float bias0 = (d.bias && nn0 < d.N) ? d.bias[nn0] : 0.f;
     const float bias1 = (d.bias && nn1 < d.N) ? d.bias[nn1] : 0.f;
@@ -163,6 +193,7 @@ int launch(ConvWinParams &p, hipStream_t stream) {
     p.tiles_l = d.L / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.cchunks = C / 8;
+    p.vec_epi = (d.N % 4 == 0) && (d.ldc % 4 == 0) && ac_aligned16(d.c) && (!d.bias || ac_aligned16(d.bias));
     static size_t configured = 0;  // grow-only attribute (benign race: same value from any thread)
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_kernel<WM, WN, C>,

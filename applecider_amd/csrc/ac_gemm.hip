@@ -32,6 +32,7 @@ constexpr int TILE_FLOATS = 128 * 32;  // both operand images are 16 KB
 struct GemmParams {
     ac_gemm_desc d;
     int tiles_m, tiles_n, nkt, kt_per_split;
+    int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
 };
 
 __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int n, float acc,
@@ -80,6 +81,57 @@ __device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (
             if (n1 < d.N) epilogue_store(d, m, n1, acc[sa][1][e], crow + c1);
         }
     });
+}
+
+// 16-byte epilogue: the wave parks each 32x64 half of its accumulator tile in 8 KB of (now idle)
+// LDS and re-reads it row-major, so every lane handles 4 consecutive columns of one row: bias /
+// aux / residual come in as float4 and C goes out as float4 — 4x fewer memory instructions than the
+// one-float-per-lane accumulator layout (the memory-bound small-K products were store-issue bound).
+__device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n, f32x4 v,
+                                             int64_t caddr) {
+    v *= d.alpha;
+    if (d.bias) v += *(const f32x4 *)(d.bias + n);
+    if (d.pre_out) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
+    if (d.act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ac_act(v[j], d.act);
+    }
+    if (d.dact) {
+        const f32x4 a = *(const f32x4 *)(d.aux + (int64_t)m * d.ld_aux + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= ac_dact(a[j], d.dact);
+    }
+    if (d.colscale) v *= *(const f32x4 *)(d.colscale + n);
+    if (d.residual) v += *(const f32x4 *)(d.residual + (int64_t)m * d.ld_res + n);
+    f32x4 *c = (f32x4 *)((float *)d.c.ptr + caddr);
+    if (d.accumulate == 1)
+        *c += v;
+    else
+        *c = v;
+}
+
+__device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+                                               float *wbuf, int row_base, int col_base, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int rsub = lane >> 4, c4 = 4 * (lane & 15);
+    const int n = col_base + c4;
+    const int64_t coff = n < d.N ? inner_off(d.c.goff, n) : 0;
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa) {
+        static_for<0, 16>([&](auto idx) {
+            constexpr int e = decltype(idx)::value;
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            wbuf[r * 64 + li] = acc[sa][0][e];
+            wbuf[r * 64 + 32 + li] = acc[sa][1][e];
+        });
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + rsub;
+            const f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4);
+            const int m = row_base + sa * 32 + r;
+            if (m < d.M && n < d.N) epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -264,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    if (p.vec_epi)
+        store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+    else
+        store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,7 +450,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    if (p.vec_epi)
+        store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+    else
+        store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -614,7 +672,10 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
         __syncthreads();
         cur ^= 1;
     }
-    store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
+    if (p.vec_epi)
+        store_tile_vec(d, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
+    else
+        store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
 }
 
 template <bool TN, int WM, int WN>
@@ -724,6 +785,17 @@ bool rowmap_aligned(const ac_rowmap &r) {
     return (r.s1 % 4 == 0) && (r.s2 % 4 == 0) && (r.s3 % 4 == 0);
 }
 
+int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
+    if (accumulate == 2 || (d.N % 4)) return 0;  // atomics keep the 128-byte-per-row lane layout
+    if (!ac_aligned16(d.c.ptr) || !rowmap_aligned(d.c.rows)) return 0;
+    if (d.bias && !ac_aligned16(d.bias)) return 0;
+    if (d.colscale && !ac_aligned16(d.colscale)) return 0;
+    if (d.pre_out && (!ac_aligned16(d.pre_out) || (d.ld_pre % 4))) return 0;
+    if (d.aux && (!ac_aligned16(d.aux) || (d.ld_aux % 4))) return 0;
+    if (d.residual && (!ac_aligned16(d.residual) || (d.ld_res % 4))) return 0;
+    return 1;  // c.goff entries are multiples of 4 by contract
+}
+
 }  // namespace
 
 extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
@@ -751,6 +823,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         p.d = d;
         if (d.split_k > 1) p.d.accumulate = 2;
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
+        p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
         // tile shape: force_tile (tests/tuning) or by output shape
         const int tile = d.tile;  // 0 auto, 1 = 128x128, 2 = 256x64, 3 = 256x128 (8 waves)
         if (d.mode == AC_GEMM_TN) {
@@ -776,7 +849,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     if (!use_mfma) {
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.
-        p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = 0;
+        p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = p.vec_epi = 0;
         int64_t total = (int64_t)d.M * d.N;
         if (d.mode == AC_GEMM_TN && d.K >= 128 && total <= 65536) {
             hipLaunchKernelGGL(gemm_simple_tn_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0,
@@ -791,6 +864,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     }
     if (d.split_k > 1) p.d.accumulate = 2;
     if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
+    p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
     p.tiles_m = (d.M + BM - 1) / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.nkt = (d.K + BK - 1) / BK;
