@@ -92,6 +92,7 @@ SIGNATURES = {
     "ac_globalmax_fwd": [_P, _P, _P, _I32, _I32, _I32, _P],
     "ac_globalmax_bwd": [_P, _P, _P, _I32, _I32, _I32, _P],
     "ac_pad_rows": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "ac_pad_rows_bf16": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_toeplitz_expand": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_toeplitz_fold": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_embed_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],

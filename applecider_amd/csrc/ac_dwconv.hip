@@ -1,43 +1,93 @@
 // Depthwise 7x7 convolution (pad 3) on NHWC fp32 planes — the ConvNeXt block's
 // spatial mixing (timm convnext_tiny, called from astrominn.py:12-17).
 //
-// HBM-bound (49 MAC per element).  A workgroup owns one 32-channel slice of a
-// sample: the whole H x W x 32 plane sits in LDS (15x15x32 fp32 = 28.8 KB for
-// stage 0), every HBM byte is read once as 128-byte lines and written once.
-// Thread = (channel c = t&31, pixel slot t>>5): LDS reads are lane-contiguous
-// (conflict free), the 49 taps of channel c live in registers.
+// HBM-bound by arithmetic (49 MAC per element, 24.5 FLOP/B at bf16 — SURVEY §8d).  A workgroup owns
+// one 32-channel slice of a sample: the zero-haloed H x W x 32 plane sits in LDS, every HBM byte is
+// read once as 128-byte lines and written once.  Thread = (channel c = t&31, work item): an item is
+// XS adjacent output pixels of one row, so a row of XS+6 LDS reads feeds 7*XS FMAs (register
+// tiling: ~15 LDS reads per output instead of 49); the 49 taps of channel c live in registers.
 #include "ac_common.h"
 
 namespace {
 
 constexpr int CG = 32;  // channels per workgroup
-// padded plane (3-pixel zero halo) so the 49-tap loops carry no bounds checks
-__host__ __device__ inline int padded_elems(int H, int W) { return (H + 6) * (W + 6) * CG; }
 
-__device__ __forceinline__ void load_padded_plane(float *plane, const float *src, int H, int W,
-                                                  int C, int cglob, bool cvalid, int c, int ps) {
-    const int Wp = W + 6, np = (H + 6) * Wp;
-    for (int q = ps; q < np; q += 8) {
-        const int yy = q / Wp - 3, xx = q % Wp - 3;
-        float v = 0.f;
-        if (cvalid && yy >= 0 && yy < H && xx >= 0 && xx < W)
-            v = src[(int64_t)(yy * W + xx) * C + cglob];
-        plane[q * CG + c] = v;
+struct Geo {
+    int H, W, C, nseg, Wp, np;  // nseg segments per row, padded pitch (pixels), padded plane pixels
+};
+template <int XS>
+__host__ __device__ inline Geo make_geo(int H, int W, int C) {
+    Geo g;
+    g.H = H;
+    g.W = W;
+    g.C = C;
+    g.nseg = (W + XS - 1) / XS;
+    g.Wp = g.nseg * XS + 6;
+    g.np = (H + 6) * g.Wp;
+    return g;
+}
+
+// Fill the zero-haloed plane: halo cells are LDS stores only; the interior is fetched eight pixels
+// at a time per thread so that eight independent 128-byte-line loads are in flight per wave (the
+// naive one-load-one-store loop was latency bound at 2 workgroups per CU).
+__device__ __forceinline__ void load_padded_plane(float *plane, const float *src, const Geo &g,
+                                                  int cglob, bool cvalid, int c, int ps) {
+    for (int q = ps; q < g.np; q += 8) {
+        const int yy = q / g.Wp - 3, xx = q % g.Wp - 3;
+        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) plane[q * CG + c] = 0.f;
+    }
+    const int HW = g.H * g.W;
+    for (int p0 = ps; p0 < HW; p0 += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 8 * u;
+            v[u] = (cvalid && p < HW) ? src[(int64_t)p * g.C + cglob] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 8 * u;
+            if (p < HW) {
+                const int py = p / g.W, px = p - py * g.W;
+                plane[((py + 3) * g.Wp + px + 3) * CG + c] = v[u];
+            }
+        }
     }
 }
 
+// out[o] += sum_{ky,kx} W(ky,kx) * plane[(y+ky), (x0+o+kx)] with W = taps (forward) or the taps
+// flipped on both axes (input gradient).  `pp` points at padded pixel (y, x0).
+template <int XS, bool FLIP>
+__device__ __forceinline__ void conv_rows(const float *pp, int Wp, const float (&wt)[49],
+                                          float (&out)[XS]) {
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        float in[XS + 6];
+#pragma unroll
+        for (int j = 0; j < XS + 6; ++j) in[j] = pp[(ky * Wp + j) * CG];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float w = FLIP ? wt[(6 - ky) * 7 + (6 - kx)] : wt[ky * 7 + kx];
+#pragma unroll
+            for (int o = 0; o < XS; ++o) out[o] = fmaf(w, in[o + kx], out[o]);
+        }
+    }
+}
+
+template <int XS>
 __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             const float *__restrict__ bias,
                                                             float *__restrict__ y, int H, int W,
                                                             int C) {
-    extern __shared__ __attribute__((aligned(16))) float plane[];  // [(H+6)*(W+6)][32]
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    const Geo g = make_geo<XS>(H, W, C);
     const int b = blockIdx.x, cg = blockIdx.y;
     const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const int cglob = cg * CG + c;
     const bool cvalid = cglob < C;
-    const int HW = H * W, Wp = W + 6;
-    load_padded_plane(plane, x + (int64_t)b * HW * C, H, W, C, cglob, cvalid, c, ps);
+    const int HW = H * W;
+    load_padded_plane(plane, x + (int64_t)b * HW * C, g, cglob, cvalid, c, ps);
     float wt[49];
 #pragma unroll
     for (int k = 0; k < 49; ++k) wt[k] = cvalid ? w[k * C + cglob] : 0.f;
@@ -45,24 +95,26 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restr
     __syncthreads();
     if (!cvalid) return;
     float *yb = y + (int64_t)b * HW * C;
-    for (int p = ps; p < HW; p += 8) {
-        const int py = p / W, px = p - py * W;
-        const float *pp = plane + (py * Wp + px) * CG + c;  // tap (0,0) of this pixel
-        float acc = bv;
+    const int items = H * g.nseg;
+    for (int it = ps; it < items; it += 8) {
+        const int py = it / g.nseg, x0 = (it % g.nseg) * XS;
+        float out[XS];
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
+        for (int o = 0; o < XS; ++o) out[o] = bv;
+        conv_rows<XS, false>(plane + (py * g.Wp + x0) * CG + c, g.Wp, wt, out);
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) acc = fmaf(wt[ky * 7 + kx], pp[(ky * Wp + kx) * CG], acc);
-        yb[(int64_t)p * C + cglob] = acc;
+        for (int o = 0; o < XS; ++o)
+            if (x0 + o < W) yb[(int64_t)(py * W + x0 + o) * C + cglob] = out[o];
     }
 }
 
 // Backward.  A workgroup loops over SPB samples of one 32-channel slice.  Per sample:
-//   phase 1: padded dy plane in LDS -> dx[p] = sum_k w[k] * dy[p - (k - 3)]
-//   phase 2: padded x plane in LDS  -> dw[k] += dy[p] * x[p + (k - 3)]   (dy[p] re-read from L2)
-// The 49 dw partial sums (+ dbias) of the thread's channel stay in registers across the
-// samples, so the global atomics are 1/SPB of the per-sample count.
+//   phase 1: padded dy plane in LDS -> dx = correlation of dy with the flipped taps
+//   phase 2: padded x plane in LDS  -> dw[ky,kx] += sum_o dy[o] * x[o + (ky-3, kx-3)]  (dy from L2)
+// The 49 dw partial sums (+ dbias) of the thread's channel stay in registers across the samples,
+// so the global atomics are 1/SPB of the per-sample count.
 constexpr int SPB = 4;
+template <int XS>
 __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restrict__ dy,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w,
@@ -71,11 +123,13 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
                                                             float *__restrict__ dbias, int B, int H,
                                                             int W, int C) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
-    const int HW = H * W, Wp = W + 6;
+    const Geo g = make_geo<XS>(H, W, C);
+    const int HW = H * W;
     const int cg = blockIdx.y;
     const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const int cglob = cg * CG + c;
     const bool cvalid = cglob < C;
+    const int items = H * g.nseg;
     float wt[49], dwacc[49];
     float dbacc = 0.f;
 #pragma unroll
@@ -90,36 +144,46 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
         const float *dyb = dy + (int64_t)b * HW * C;
         float *dxb = dx + (int64_t)b * HW * C;
         __syncthreads();
-        load_padded_plane(plane, dyb, H, W, C, cglob, cvalid, c, ps);
+        load_padded_plane(plane, dyb, g, cglob, cvalid, c, ps);
         __syncthreads();
         if (cvalid) {
-            for (int p = ps; p < HW; p += 8) {
-                const int py = p / W, px = p - py * W;
-                // dy[p - (k-3)] = padded[(py + 6 - ky), (px + 6 - kx)]
-                const float *pp = plane + ((py + 6) * Wp + (px + 6)) * CG + c;
-                float acc = 0.f;
+            for (int it = ps; it < items; it += 8) {
+                const int py = it / g.nseg, x0 = (it % g.nseg) * XS;
+                float out[XS];
 #pragma unroll
-                for (int ky = 0; ky < 7; ++ky)
+                for (int o = 0; o < XS; ++o) out[o] = 0.f;
+                conv_rows<XS, true>(plane + (py * g.Wp + x0) * CG + c, g.Wp, wt, out);
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx)
-                        acc = fmaf(wt[ky * 7 + kx], pp[-(ky * Wp + kx) * CG], acc);
-                dxb[(int64_t)p * C + cglob] = acc;
+                for (int o = 0; o < XS; ++o)
+                    if (x0 + o < W) dxb[(int64_t)(py * W + x0 + o) * C + cglob] = out[o];
             }
         }
         __syncthreads();
-        load_padded_plane(plane, xb, H, W, C, cglob, cvalid, c, ps);
+        load_padded_plane(plane, xb, g, cglob, cvalid, c, ps);
         __syncthreads();
         if (cvalid) {
-            for (int p = ps; p < HW; p += 8) {
-                const int py = p / W, px = p - py * W;
-                const float dv = dyb[(int64_t)p * C + cglob];
-                const float *pp = plane + (py * Wp + px) * CG + c;
-                dbacc += dv;
+            for (int it = ps; it < items; it += 8) {
+                const int py = it / g.nseg, x0 = (it % g.nseg) * XS;
+                float d[XS];
 #pragma unroll
-                for (int ky = 0; ky < 7; ++ky)
+                for (int o = 0; o < XS; ++o) {
+                    d[o] = (x0 + o < W) ? dyb[(int64_t)(py * W + x0 + o) * C + cglob] : 0.f;
+                    dbacc += d[o];
+                }
+                const float *pp = plane + (py * g.Wp + x0) * CG + c;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx)
-                        dwacc[ky * 7 + kx] = fmaf(dv, pp[(ky * Wp + kx) * CG], dwacc[ky * 7 + kx]);
+                for (int ky = 0; ky < 7; ++ky) {
+                    float in[XS + 6];
+#pragma unroll
+                    for (int j = 0; j < XS + 6; ++j) in[j] = pp[(ky * g.Wp + j) * CG];
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        float a = dwacc[ky * 7 + kx];
+#pragma unroll
+                        for (int o = 0; o < XS; ++o) a = fmaf(d[o], in[o + kx], a);
+                        dwacc[ky * 7 + kx] = a;
+                    }
+                }
             }
         }
     }
@@ -145,31 +209,50 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
     }
 }
 
-}  // namespace
-
-extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y,
-                                int32_t B, int32_t H, int32_t W, int32_t C, ac_stream_t stream) {
-    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
-    size_t lds = (size_t)padded_elems(H, W) * sizeof(float);
-    if (lds > 65536) return AC_EINVAL;  // up to 16x16 planes (ConvNeXt stage 0 is 15x15)
-    dim3 grid(B, (C + CG - 1) / CG);
-    hipLaunchKernelGGL(dwconv7x7_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias,
-                       y, H, W, C);
+template <int XS>
+int launch_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W,
+               int C, hipStream_t stream) {
+    const Geo g = make_geo<XS>(H, W, C);
+    const size_t lds = (size_t)g.np * CG * sizeof(float);
+    if (lds > 65536) return AC_EINVAL;  // up to ~16x16 planes (ConvNeXt stage 0 is 15x15)
+    hipLaunchKernelGGL(dwconv7x7_fwd_kernel<XS>, dim3(B, (C + CG - 1) / CG), dim3(256), lds, stream,
+                       x, w, bias, y, H, W, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+template <int XS>
+int launch_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias,
+               int B, int H, int W, int C, hipStream_t stream) {
+    const Geo g = make_geo<XS>(H, W, C);
+    const size_t planes = (size_t)g.np * CG * sizeof(float);
+    const size_t red = (size_t)8 * 50 * CG * sizeof(float);
+    const size_t lds = planes > red ? planes : red;
+    if (lds > 65536) return AC_EINVAL;
+    hipLaunchKernelGGL(dwconv7x7_bwd_kernel<XS>, dim3((B + SPB - 1) / SPB, (C + CG - 1) / CG),
+                       dim3(256), lds, stream, dy, x, w, dx, dw, dbias, B, H, W, C);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
 
+}  // namespace
+
+extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y,
+                                int32_t B, int32_t H, int32_t W, int32_t C, ac_stream_t stream_) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (W == 1) return launch_fwd<1>(x, w, bias, y, B, H, W, C, stream);
+    if (W <= 3) return launch_fwd<3>(x, w, bias, y, B, H, W, C, stream);
+    if (W == 7) return launch_fwd<7>(x, w, bias, y, B, H, W, C, stream);
+    return launch_fwd<5>(x, w, bias, y, B, H, W, C, stream);
+}
+
 extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w, float *dx,
                                 float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
-                                int32_t C, ac_stream_t stream) {
+                                int32_t C, ac_stream_t stream_) {
     if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
-    dim3 grid((B + SPB - 1) / SPB, (C + CG - 1) / CG);
-    size_t planes = (size_t)padded_elems(H, W) * sizeof(float);
-    size_t red = (size_t)8 * 50 * CG * sizeof(float);
-    size_t lds = planes > red ? planes : red;
-    if (lds > 65536) return AC_EINVAL;
-    hipLaunchKernelGGL(dwconv7x7_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, dy, x, w,
-                       dx, dw, dbias, B, H, W, C);
-    AC_CHECK_LAUNCH();
-    return AC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    return launch_bwd<5>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
 }

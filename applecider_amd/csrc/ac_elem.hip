@@ -1,5 +1,6 @@
 // Elementwise / layout / pooling kernels (all HBM-bound; grid-stride, coalesced).
 #include "ac_common.h"
+#include <hip/hip_bf16.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -210,6 +211,46 @@ __global__ void pad_rows_kernel(const float *x, float *y, int B, int L, int C, i
     }
 }
 
+// same, emitting bf16 (the conv operands of the bf16 matrix-core path): 8 channels per thread
+__global__ void pad_rows_bf16_kernel(const float *x, unsigned short *y, int B, int L, int C,
+                                     int pad_lo, int Lp) {
+    const int C8 = C >> 3;
+    const int64_t n = (int64_t)B * Lp * C8;
+    GSTRIDE(i, n) {
+        int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        int lp = (int)(t % Lp);
+        int64_t b = t / Lp;
+        int l = lp - pad_lo;
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (l >= 0 && l < L) {
+            const float *src = x + (b * L + l) * C + 8 * c8;
+            const f32x4 a = *(const f32x4 *)src, bb = *(const f32x4 *)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __hip_bfloat16 h0 = __float2bfloat16(a[j]), h1 = __float2bfloat16(bb[j]);
+                o[j] = *reinterpret_cast<short *>(&h0);
+                o[4 + j] = *reinterpret_cast<short *>(&h1);
+            }
+        }
+        *(s16x8 *)(y + i * 8) = o;
+    }
+}
+__global__ void pad_rows_bf16_scalar_kernel(const float *x, unsigned short *y, int B, int L, int C,
+                                            int pad_lo, int Lp) {
+    const int64_t n = (int64_t)B * Lp * C;
+    GSTRIDE(i, n) {
+        int c = (int)(i % C);
+        int64_t t = i / C;
+        int lp = (int)(t % Lp);
+        int64_t b = t / Lp;
+        int l = lp - pad_lo;
+        __hip_bfloat16 h = __float2bfloat16((l >= 0 && l < L) ? x[(b * L + l) * C + c] : 0.f);
+        y[i] = *reinterpret_cast<unsigned short *>(&h);
+    }
+}
+
 // wexp[(r*Cout + co), t'] = w[co, t' - r]  for 0 <= t'-r < k, else 0
 __global__ void toeplitz_expand_kernel(const float *w, float *wexp, int Cout, int k, int Kp,
                                        int shift) {
@@ -397,6 +438,15 @@ extern "C" int ac_pad_rows(const float *x, float *y, int32_t B, int32_t L, int32
                            int32_t pad_lo, int32_t Lp, ac_stream_t stream) {
     if (!x || !y || B <= 0 || L <= 0 || C <= 0 || pad_lo < 0 || Lp < L + pad_lo) return AC_EINVAL;
     EW_LAUNCH(pad_rows_kernel, (int64_t)B * Lp * C, x, y, B, L, C, pad_lo, Lp);
+}
+extern "C" int ac_pad_rows_bf16(const float *x, void *y, int32_t B, int32_t L, int32_t C,
+                                int32_t pad_lo, int32_t Lp, ac_stream_t stream) {
+    if (!x || !y || B <= 0 || L <= 0 || C <= 0 || pad_lo < 0 || Lp < L + pad_lo) return AC_EINVAL;
+    if (C % 8 == 0 && ac_aligned16(x) && ac_aligned16(y))
+        EW_LAUNCH(pad_rows_bf16_kernel, (int64_t)B * Lp * (C / 8), x, (unsigned short *)y, B, L, C,
+                  pad_lo, Lp);
+    EW_LAUNCH(pad_rows_bf16_scalar_kernel, (int64_t)B * Lp * C, x, (unsigned short *)y, B, L, C, pad_lo,
+              Lp);
 }
 extern "C" int ac_toeplitz_expand(const float *w, float *wexp, int32_t Cout, int32_t k,
                                   int32_t Kp, int32_t shift, ac_stream_t stream) {

@@ -530,10 +530,13 @@ struct LoaderRC16 {
     const unsigned short *ptr;
     ac_rowmap rows;
     int64_t io;
-    bool cv;
+    bool cv, fast;
     int outer_n, t;
+    // 1- and 2-level row maps advance incrementally (one add + compare per K tile) instead of
+    // re-deriving (batch, position) with integer divisions for every chunk of every K tile
+    int q1[NCH], rem[NCH];
     __device__ __forceinline__ void init(const ac_mat &m, int outer_extent, int inner_extent,
-                                         int origin, int tid) {
+                                         int origin, int tid, int kt0) {
         ptr = (const unsigned short *)m.ptr;
         rows = m.rows;
         outer_n = outer_extent;
@@ -541,13 +544,39 @@ struct LoaderRC16 {
         const int col = origin + 8 * (t % CPR);
         cv = col < inner_extent;
         io = cv ? (m.goff ? (int64_t)m.goff[col >> 5] + (col & 31) : (int64_t)col) : 0;
+        fast = rows.r1 == 0 || rows.r2 == rows.r1;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int kg = kt0 * BK16 + t / CPR + KSTEP * i;
+            if (rows.r1 == 0) {
+                q1[i] = 0;
+                rem[i] = kg;
+            } else {
+                q1[i] = kg / rows.r1;
+                rem[i] = kg - q1[i] * rows.r1;
+            }
+        }
     }
-    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) const {
+    // loads K tile kt; must be called with consecutive kt starting at kt0
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int kg = kt * BK16 + t / CPR + KSTEP * i;
+            int64_t ra;
+            if (fast) {
+                ra = (int64_t)q1[i] * rows.s1 + (int64_t)rem[i] * rows.s3;
+                rem[i] += BK16;
+                if (rows.r1 != 0) {
+                    while (rem[i] >= rows.r1) {
+                        rem[i] -= rows.r1;
+                        ++q1[i];
+                    }
+                }
+            } else {
+                ra = ac_rowaddr(rows, kg < outer_n ? kg : 0);
+            }
             if (cv && kg < outer_n)
-                v[i] = *(const u32x4 *)(ptr + ac_rowaddr(rows, kg) + io);
+                v[i] = *(const u32x4 *)(ptr + ra + io);
             else
                 v[i] = u32x4{0u, 0u, 0u, 0u};
         }
@@ -615,9 +644,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     using LB = typename std::conditional<TN, LoaderRC16<Cfg::TNn, Cfg::NT>, LoaderKC16<Cfg::TNn, Cfg::NT>>::type;
     LA la;
     LB lb;
-    if (TN) {
-        la.init(d.a, d.K, d.M, tm * Cfg::TM, t);
-        lb.init(d.b, d.K, d.N, tn * Cfg::TNn, t);
+    if constexpr (TN) {
+        la.init(d.a, d.K, d.M, tm * Cfg::TM, t, kt_begin);
+        lb.init(d.b, d.K, d.N, tn * Cfg::TNn, t, kt_begin);
     } else {
         la.init(d.a, d.M, d.K, tm * Cfg::TM, t);
         lb.init(d.b, d.N, d.K, tn * Cfg::TNn, t);

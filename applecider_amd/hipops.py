@@ -792,6 +792,13 @@ def _pad_rows(x, B, L, Cn, pad_lo, Lp):
     return y
 
 
+def _pad_rows16(x, B, L, Cn, pad_lo, Lp):
+    y = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.bfloat16)
+    _lib.check(_lib_().ac_pad_rows_bf16(_p(x), _p(y), B, L, Cn, pad_lo, Lp, _stream()),
+               "ac_pad_rows_bf16")
+    return y
+
+
 class _ConvGroup1d(Function):
     """The parallel 'same' Conv1d bank of a SpectraNetBlock (spectranet.py:18-20,25):
     ycat[b, l, j*Cout + co] = bias_j[co] + sum_{t,ci} x[b, l + t - k_j//2, ci] * w_j[co, t, ci].
@@ -833,9 +840,7 @@ class _ConvGroup1d(Function):
                 raise ValueError("Cin == 1 path needs L % 8 == 0")
             al = 8 if b16 else 4  # 16-byte granules in operand elements
             Lp = (L + 2 * Pmax + 48 + 7) // 8 * 8
-            xpad = _pad_rows(x, B, L, 1, Pmax, Lp)
-            if b16:
-                xpad = cast16(xpad)
+            xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, 1, Pmax, Lp)
             Lq = L // 8
             saved_meta = []
             for j, k in enumerate(ksizes):
@@ -863,9 +868,7 @@ class _ConvGroup1d(Function):
             if Cin % 32:
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
             Lp = L + 2 * Pmax
-            xpad = _pad_rows(x, B, L, Cin, Pmax, Lp)
-            if b16:
-                xpad = cast16(xpad)
+            xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 wop = cast16_w(ws[j]) if b16 else ws[j]
@@ -936,7 +939,17 @@ class _ConvGroup1d(Function):
         dx = None
         b16 = ctx.b16
         mth = _lib.MATH_BF16_IN if b16 else None
-        dyop = cast16(dycat) if b16 else dycat  # A operand of the dW products
+        need_dx = Cin != 1 and ctx.needs_input_grad[0]
+        Lpd = L + 2 * Pmax
+        if need_dx:
+            # one zero-padded (bf16 in bf16 mode) copy of d(ycat) serves the input-gradient products
+            # (as the window / gathered operand) and the weight-gradient products (rows Pmax..Pmax+L)
+            dypad = (_pad_rows16 if b16 else _pad_rows)(dycat, B, L, Ncat, Pmax, Lpd)
+        if b16 and need_dx:
+            dy_mat = lambda j: mat(_p(dypad, Pmax * Ncat + j * Cout), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat)
+        else:
+            dyop = cast16(dycat) if b16 else dycat  # A operand of the dW products
+            dy_mat = lambda j: mat(_p(dyop, j * Cout), Ncat)
         if Cin == 1:
             Lq = L // 8
             for j, k in enumerate(ksizes):
@@ -953,11 +966,7 @@ class _ConvGroup1d(Function):
                 raise NotImplementedError("input gradient of the Cin == 1 conv bank is not needed "
                                           "on the path (the flux is a network input)")
         else:
-            if ctx.needs_input_grad[0]:
-                Lpd = L + 2 * Pmax
-                dypad = _pad_rows(dycat, B, L, Ncat, Pmax, Lpd)
-                if b16:
-                    dypad = cast16(dypad)
+            if need_dx:
                 dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
             for j, k in enumerate(ksizes):
                 p = k // 2
@@ -990,7 +999,7 @@ class _ConvGroup1d(Function):
                 wsink = _sink(ctx.params[0][j])
                 dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev,
                                                                   dtype=torch.float32)
-                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, mat(_p(dyop, j * Cout), Ncat),
+                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
                      mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L),
                      math=mth)

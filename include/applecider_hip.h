@@ -237,6 +237,9 @@ int ac_globalmax_bwd(const float *dy, const int32_t *idx, float *dx, int32_t B, 
 /* flux [B, L] -> zero-padded [B, Lp] at offset pad (stage-1 Toeplitz operand). */
 int ac_pad_rows(const float *x, float *y, int32_t B, int32_t L, int32_t C, int32_t pad_lo,
                 int32_t Lp, ac_stream_t stream);
+/* same with a bf16 destination (operand of the bf16 matrix-core kernels). */
+int ac_pad_rows_bf16(const float *x, void *y, int32_t B, int32_t L, int32_t C, int32_t pad_lo,
+                     int32_t Lp, ac_stream_t stream);
 /* stage-1 (Cin = 1) weight expansion for the 8-phase Toeplitz GEMM:
  *   w[Cout, k] -> wexp[8*Cout, Kp],  wexp[(r,co), t'] = w[co, t' - r - shift]  (0 elsewhere)
  * and the matching gradient fold dw[co,t] = sum_r dwexp[(r,co), t + r + shift].
