@@ -74,3 +74,13 @@ __device__ __forceinline__ int64_t ac_rowaddr(const ac_rowmap &m, int r) {
     int q3 = rem - q2 * m.r2;
     return (int64_t)q1 * m.s1 + (int64_t)q2 * m.s2 + (int64_t)q3 * m.s3;
 }
+
+// Explicit global-address-space loads.  Pointers that travel through by-value kernel-argument
+// structs are not always inferred as global by hipcc; a FLAT load counts on lgkmcnt as well as
+// vmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs (meant for the LDS fragment reads)
+// also waits for every prefetch in flight and serialises the whole software pipeline.
+template <typename V, typename T>
+__device__ __forceinline__ V ac_gload(const T *p) {
+    typedef __attribute__((address_space(1))) const V gV;
+    return *(gV *)(p);
+}

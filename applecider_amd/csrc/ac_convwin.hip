@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
         const int total = W * (C / 8);
         for (int idx = t; idx < total; idx += NT) {
             const int r = idx / (C / 8), cc = idx % (C / 8);
-            const u32x4 v = *(const u32x4 *)(a + (int64_t)r * d.a_row_stride + cc * 8);
+            const u32x4 v = ac_gload<u32x4>(a + (int64_t)r * d.a_row_stride + cc * 8);
             *(u32x4 *)(win + win_off<C>(r, cc)) = v;
         }
     }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
     auto wload = [&](int kt, u32x4 (&v)[BCH]) {
         const int64_t ko = koff(kt);
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) v[i] = *(const u32x4 *)(wptr + wbase[i] + ko);
+        for (int i = 0; i < BCH; ++i) v[i] = ac_gload<u32x4>(wptr + wbase[i] + ko);
     };
     auto wstore = [&](unsigned short *tile, const u32x4 (&v)[BCH]) {
         const int c = t & 7;

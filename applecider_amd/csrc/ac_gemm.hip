@@ -177,26 +177,28 @@ struct Loader {
         }
     }
 
+    // Loads are UNCONDITIONAL (addresses clamped into the operand) and masked afterwards: a
+    // "load or zero" select makes hipcc branch around every load and wait for each one in turn
+    // (cdna_hip_programming.md section 5, trap (c)) - a K tile then costs 4-8 dependent round trips.
     __device__ __forceinline__ void load(int kt, f32x4 (&v)[4]) const {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (KC) {
-            int k = kt * BK + 4 * (t & 7);
-            bool kv = k < inner_n;
-            int64_t ko = goff ? (int64_t)goff[kt] : (int64_t)kt * BK;
+            const int k = kt * BK + 4 * (t & 7);
+            const bool kv = k < inner_n;
+            const int ktc = kv ? kt : 0;
+            const int64_t ko = kv ? (goff ? (int64_t)goff[ktc] : (int64_t)ktc * BK) : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (kv)
-                    v[i] = *(const f32x4 *)(ptr + base[i] + ko);
-                else
-                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 val = ac_gload<f32x4>(ptr + base[i] + (kv ? ko : -4 * (t & 7)));
+                v[i] = kv ? val : zero;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int kg = kt * BK + (t >> 5) + 8 * i;
-                if (ok[i] && kg < outer_n)
-                    v[i] = *(const f32x4 *)(ptr + ac_rowaddr(rows, kg) + base[i]);
-                else
-                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int kg = kt * BK + (t >> 5) + 8 * i;
+                const bool okk = ok[i] && kg < outer_n;
+                const f32x4 val = ac_gload<f32x4>(ptr + ac_rowaddr(rows, kg < outer_n ? kg : outer_n - 1) + base[i]);
+                v[i] = okk ? val : zero;
             }
         }
     }
@@ -492,24 +494,29 @@ struct LoaderKC16 {
             base[i] = ac_rowaddr(m.rows, r);
         }
     }
-    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) const {
+    // Raw (unconditional, clamped) loads; the K-tail mask is applied when the registers are
+    // written to LDS one iteration later, so nothing consumes the loaded values in the iteration
+    // that issued them (a select right after the load made hipcc wait for its own prefetch).
+    template <bool G>
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH], unsigned &mask) const {
         const int e = kt * BK16 + 8 * (t & 7);
         const bool kv = e < inner_n;
-        const int64_t ko = goff ? (int64_t)goff[e >> 5] + (e & 31) : (int64_t)e;
+        const int ec = kv ? e : 0;
+        int64_t ko = ec;
+        if constexpr (G) ko = (int64_t)ac_gload<int32_t>(goff + (ec >> 5)) + (ec & 31);
+        mask = kv ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            if (kv)
-                v[i] = *(const u32x4 *)(ptr + base[i] + ko);
-            else
-                v[i] = u32x4{0u, 0u, 0u, 0u};
-        }
+        for (int i = 0; i < NCH; ++i) v[i] = ac_gload<u32x4>(ptr + base[i] + ko);
     }
-    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH]) const {
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH],
+                                          unsigned mask) const {
         const int c = t & 7;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int r = (t >> 3) + (NT / 8) * i;
-            *(u32x4 *)(tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = v[i];
+            u32x4 w = v[i];
+            w[0] &= mask; w[1] &= mask; w[2] &= mask; w[3] &= mask;
+            *(u32x4 *)(tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = w;
         }
     }
 };
@@ -544,7 +551,7 @@ struct LoaderRC16 {
         const int col = origin + 8 * (t % CPR);
         cv = col < inner_extent;
         io = cv ? (m.goff ? (int64_t)m.goff[col >> 5] + (col & 31) : (int64_t)col) : 0;
-        fast = rows.r1 == 0 || rows.r2 == rows.r1;
+        fast = rows.r1 == 0 || (rows.r2 == rows.r1 && rows.r1 >= BK16);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int kg = kt0 * BK16 + t / CPR + KSTEP * i;
@@ -557,35 +564,39 @@ struct LoaderRC16 {
             }
         }
     }
-    // loads K tile kt; must be called with consecutive kt starting at kt0
-    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH]) {
+    // loads K tile kt (raw, clamped); must be called with consecutive kt starting at kt0.
+    // mask bit i = chunk i is inside the operand (applied by store()).
+    template <bool G>
+    __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH], unsigned &mask) {
+        mask = 0u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int kg = kt * BK16 + t / CPR + KSTEP * i;
+            const bool in = kg < outer_n;
             int64_t ra;
             if (fast) {
                 ra = (int64_t)q1[i] * rows.s1 + (int64_t)rem[i] * rows.s3;
                 rem[i] += BK16;
-                if (rows.r1 != 0) {
-                    while (rem[i] >= rows.r1) {
-                        rem[i] -= rows.r1;
-                        ++q1[i];
-                    }
-                }
+                const bool wrap = rows.r1 != 0 && rem[i] >= rows.r1;  // r1 >= 64 on the fast path
+                rem[i] -= wrap ? rows.r1 : 0;
+                q1[i] += wrap ? 1 : 0;
             } else {
-                ra = ac_rowaddr(rows, kg < outer_n ? kg : 0);
+                ra = ac_rowaddr(rows, in ? kg : 0);
             }
-            if (cv && kg < outer_n)
-                v[i] = *(const u32x4 *)(ptr + ra + io);
-            else
-                v[i] = u32x4{0u, 0u, 0u, 0u};
+            ra = in ? ra : 0;  // keep the load inside the operand
+            v[i] = ac_gload<u32x4>(ptr + ra + io);
+            mask |= (cv && in) ? (1u << i) : 0u;
         }
     }
-    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH]) const {
+    __device__ __forceinline__ void store(unsigned short *tile, const u32x4 (&v)[NCH],
+                                          unsigned mask) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int k = t / CPR + KSTEP * i;
-            *(u32x4 *)(tile + k * PITCH + 8 * (t % CPR)) = v[i];
+            const unsigned m = (mask >> i) & 1u ? 0xFFFFFFFFu : 0u;
+            u32x4 w = v[i];
+            w[0] &= m; w[1] &= m; w[2] &= m; w[3] &= m;
+            *(u32x4 *)(tile + k * PITCH + 8 * (t % CPR)) = w;
         }
     }
 };
@@ -660,21 +671,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u32x4 ra[LA::NCH], rb[LB::NCH];
-    la.load(kt_begin, ra);
-    lb.load(kt_begin, rb);
-    la.store(sm, ra);
-    lb.store(sm + Cfg::A_TILE, rb);
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) {
-            la.load(kt + 1, ra);
-            lb.load(kt + 1, rb);
-        }
-        const unsigned short *at = sm + cur * Cfg::STAGE, *bt = at + Cfg::A_TILE;
+    // Software pipeline, prefetch distance 2: while tile kt feeds the matrix cores, tile kt+1 is
+    // landing in one register set and the loads of tile kt+2 are issued into the other (a K-tile
+    // iteration was latency bound at ~1.3 us with distance 1: the global loads of the next tile
+    // only had the 0.2 us of MFMA work to hide under).  Two LDS stages, one barrier per tile.
+    auto compute = [&](const unsigned short *at, const unsigned short *bt) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 a0, a1, b0, b1;
@@ -694,13 +695,54 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) {
-            la.store(sm + (cur ^ 1) * Cfg::STAGE, ra);
-            lb.store(sm + (cur ^ 1) * Cfg::STAGE + Cfg::A_TILE, rb);
-        }
+    };
+    unsigned short *S0 = sm, *S1 = sm + Cfg::STAGE;
+    // Steady-state loop without data-dependent branches: the offset-table lookups are compiled in or
+    // out per operand (AG / BG), and tail iterations re-load the last tile into an unused register
+    // set / LDS stage instead of skipping, so that each half of the loop is ONE basic block and
+    // hipcc uses counted vmcnt waits (a load inside an `if` made it wait vmcnt(0) in front of the LDS
+    // store, i.e. for the prefetch it had just issued).
+    auto run = [&](auto AGt, auto BGt) {
+        constexpr bool AG = decltype(AGt)::value, BG = decltype(BGt)::value;
+        u32x4 ra0[LA::NCH], rb0[LB::NCH], ra1[LA::NCH], rb1[LB::NCH];
+        unsigned ma0, mb0, ma1, mb1;
+        la.template load<AG>(kt_begin, ra0, ma0);
+        lb.template load<BG>(kt_begin, rb0, mb0);
+        la.store(S0, ra0, ma0);
+        lb.store(S0 + Cfg::A_TILE, rb0, mb0);
         __syncthreads();
-        cur ^= 1;
-    }
+        // Tiles past the end of this block's K range are still loaded (valid memory: rows / k
+        // beyond the operand are redirected to offset 0 and masked) and land in a stage that is
+        // never multiplied; the TN loader's incremental row state needs strictly consecutive calls.
+        la.template load<AG>(kt_begin + 1, ra0, ma0);
+        lb.template load<BG>(kt_begin + 1, rb0, mb0);
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            la.template load<AG>(kt + 2, ra1, ma1);
+            lb.template load<BG>(kt + 2, rb1, mb1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMA phase
+            compute(S0, S0 + Cfg::A_TILE);
+            la.store(S1, ra0, ma0);
+            lb.store(S1 + Cfg::A_TILE, rb0, mb0);
+            __syncthreads();
+            if (kt + 1 >= kt_end) break;
+            la.template load<AG>(kt + 3, ra0, ma0);
+            lb.template load<BG>(kt + 3, rb0, mb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S1, S1 + Cfg::A_TILE);
+            la.store(S0, ra1, ma1);
+            lb.store(S0 + Cfg::A_TILE, rb1, mb1);
+            __syncthreads();
+        }
+    };
+    const bool ag = !TN && d.a.goff != nullptr, bg = !TN && d.b.goff != nullptr;
+    if (ag && bg)
+        run(std::true_type{}, std::true_type{});
+    else if (ag)
+        run(std::true_type{}, std::false_type{});
+    else if (bg)
+        run(std::false_type{}, std::true_type{});
+    else
+        run(std::false_type{}, std::false_type{});
     if (p.vec_epi)
         store_tile_vec(d, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
     else
@@ -846,7 +888,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         auto al8 = [](const ac_rowmap &r) { return r.s1 % 8 == 0 && r.s2 % 8 == 0 && r.s3 % 8 == 0; };
         const int ai = d.mode == AC_GEMM_TN ? d.M : d.K, bi = d.mode == AC_GEMM_TN ? d.N : d.K;
         if (!ac_aligned16(d.a.ptr) || !ac_aligned16(d.b.ptr) || !al8(d.a.rows) || !al8(d.b.rows) ||
-            (ai % 8) || (bi % 8) || d.force_simple)
+            (ai % 8) || (bi % 8) || d.force_simple == 1)
             return AC_EALIGN;
         GemmParams p;
         p.d = d;
