@@ -67,6 +67,8 @@ class GradBuckets:
         self.reset()
 
     def reset(self):
+        self._seen = set()
+        self.duplicates = []
         self.pending = list(self.counts)
         self.launched = [False] * len(self.buckets)
         self.handles = []
@@ -82,6 +84,13 @@ class GradBuckets:
 
     def _make_hook(self, idx: int):
         def hook(_param):
+            # A parameter is counted once per backward: a gradient written through a sink is
+            # reported by the kernel wrapper, and autograd still runs the parameter's
+            # post-accumulate hook afterwards (with an undefined gradient) - the first report wins.
+            if idx in self._seen:
+                self.duplicates.append(idx)
+                return
+            self._seen.add(idx)
             b = self.bucket_of[idx]
             self.pending[b] -= 1
             if self.pending[b] == 0 and self.overlap:
