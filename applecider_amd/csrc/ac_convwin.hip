@@ -106,17 +106,10 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u32x4 rb[BCH];
-    wload(0, rb);
-    wstore(bst, rb);
-    __syncthreads();  // window + first weight tile visible
-
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) wload(kt + 1, rb);
+    // Weight stream: prefetch distance 2 through two register sets, branch-free steady state (tail
+    // iterations re-load the last tile into an unused stage), so hipcc keeps counted vmcnt waits.
+    auto compute = [&](int kt, const unsigned short *bt) {
         const int tap = kt / ctiles, cc0 = (kt % ctiles) * 8;
-        const unsigned short *bt = bst + cur * (BN * 64);
         const int r0 = wm * 64 + li + tap, r1 = r0 + 32;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -132,9 +125,26 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) wstore(bst + (cur ^ 1) * (BN * 64), rb);
+    };
+    unsigned short *S0 = bst, *S1 = bst + BN * 64;
+    const int last = nkt - 1;
+    u32x4 rb0[BCH], rb1[BCH];
+    wload(0, rb0);
+    wstore(S0, rb0);
+    __syncthreads();  // window + first weight tile visible
+    wload(1 < last ? 1 : last, rb0);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        wload(kt + 2 < last ? kt + 2 : last, rb1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt, S0);
+        wstore(S1, rb0);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 >= nkt) break;
+        wload(kt + 3 < last ? kt + 3 : last, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt + 1, S1);
+        wstore(S0, rb1);
+        __syncthreads();
     }
 
     // ---- epilogue: out[b, l0 + m, n] (+)= acc (+ bias).  The wave parks each 32x64 half of its
