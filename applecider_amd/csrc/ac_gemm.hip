@@ -497,7 +497,7 @@ struct LoaderKC16 {
     // Raw (unconditional, clamped) loads; the K-tail mask is applied when the registers are
     // written to LDS one iteration later, so nothing consumes the loaded values in the iteration
     // that issued them (a select right after the load made hipcc wait for its own prefetch).
-    template <bool G>
+    template <bool G, bool FAST = true>
     __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH], unsigned &mask) const {
         const int e = kt * BK16 + 8 * (t & 7);
         const bool kv = e < inner_n;
@@ -539,9 +539,11 @@ struct LoaderRC16 {
     int64_t io;
     bool cv, fast;
     int outer_n, t;
-    // 1- and 2-level row maps advance incrementally (one add + compare per K tile) instead of
-    // re-deriving (batch, position) with integer divisions for every chunk of every K tile
-    int q1[NCH], rem[NCH];
+    // 1- and 2-level row maps keep a running element address per chunk: one 64-bit add (+ a wrap
+    // correction when the row index crosses a batch boundary) per K tile instead of re-deriving
+    // (batch, position) with divisions and 64-bit multiplies for every chunk of every K tile
+    int64_t addr[NCH], step, wrap_fix;
+    int rem[NCH];
     __device__ __forceinline__ void init(const ac_mat &m, int outer_extent, int inner_extent,
                                          int origin, int tid, int kt0) {
         ptr = (const unsigned short *)m.ptr;
@@ -552,21 +554,24 @@ struct LoaderRC16 {
         cv = col < inner_extent;
         io = cv ? (m.goff ? (int64_t)m.goff[col >> 5] + (col & 31) : (int64_t)col) : 0;
         fast = rows.r1 == 0 || (rows.r2 == rows.r1 && rows.r1 >= BK16);
+        step = (int64_t)BK16 * rows.s3;
+        wrap_fix = rows.s1 - (int64_t)rows.r1 * rows.s3;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int kg = kt0 * BK16 + t / CPR + KSTEP * i;
             if (rows.r1 == 0) {
-                q1[i] = 0;
-                rem[i] = kg;
+                rem[i] = 0;
+                addr[i] = (int64_t)kg * rows.s3 + io;
             } else {
-                q1[i] = kg / rows.r1;
-                rem[i] = kg - q1[i] * rows.r1;
+                const int q1 = kg / rows.r1;
+                rem[i] = kg - q1 * rows.r1;
+                addr[i] = (int64_t)q1 * rows.s1 + (int64_t)rem[i] * rows.s3 + io;
             }
         }
     }
     // loads K tile kt (raw, clamped); must be called with consecutive kt starting at kt0.
     // mask bit i = chunk i is inside the operand (applied by store()).
-    template <bool G>
+    template <bool G, bool FAST = true>
     __device__ __forceinline__ void load(int kt, u32x4 (&v)[NCH], unsigned &mask) {
         mask = 0u;
 #pragma unroll
@@ -574,17 +579,18 @@ struct LoaderRC16 {
             const int kg = kt * BK16 + t / CPR + KSTEP * i;
             const bool in = kg < outer_n;
             int64_t ra;
-            if (fast) {
-                ra = (int64_t)q1[i] * rows.s1 + (int64_t)rem[i] * rows.s3;
+            if constexpr (FAST) {
+                ra = addr[i];
+                addr[i] += step;
                 rem[i] += BK16;
                 const bool wrap = rows.r1 != 0 && rem[i] >= rows.r1;  // r1 >= 64 on the fast path
                 rem[i] -= wrap ? rows.r1 : 0;
-                q1[i] += wrap ? 1 : 0;
+                addr[i] += wrap ? wrap_fix : 0;
             } else {
-                ra = ac_rowaddr(rows, in ? kg : 0);
+                ra = ac_rowaddr(rows, in ? kg : 0) + io;
             }
-            ra = in ? ra : 0;  // keep the load inside the operand
-            v[i] = ac_gload<u32x4>(ptr + ra + io);
+            ra = in ? ra : io;  // keep the load inside the operand
+            v[i] = ac_gload<u32x4>(ptr + ra);
             mask |= (cv && in) ? (1u << i) : 0u;
         }
     }
@@ -702,31 +708,31 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     // set / LDS stage instead of skipping, so that each half of the loop is ONE basic block and
     // hipcc uses counted vmcnt waits (a load inside an `if` made it wait vmcnt(0) in front of the LDS
     // store, i.e. for the prefetch it had just issued).
-    auto run = [&](auto AGt, auto BGt) {
-        constexpr bool AG = decltype(AGt)::value, BG = decltype(BGt)::value;
+    auto run = [&](auto AGt, auto BGt, auto FSt) {
+        constexpr bool AG = decltype(AGt)::value, BG = decltype(BGt)::value, FS = decltype(FSt)::value;
         u32x4 ra0[LA::NCH], rb0[LB::NCH], ra1[LA::NCH], rb1[LB::NCH];
         unsigned ma0, mb0, ma1, mb1;
-        la.template load<AG>(kt_begin, ra0, ma0);
-        lb.template load<BG>(kt_begin, rb0, mb0);
+        la.template load<AG, FS>(kt_begin, ra0, ma0);
+        lb.template load<BG, FS>(kt_begin, rb0, mb0);
         la.store(S0, ra0, ma0);
         lb.store(S0 + Cfg::A_TILE, rb0, mb0);
         __syncthreads();
         // Tiles past the end of this block's K range are still loaded (valid memory: rows / k
         // beyond the operand are redirected to offset 0 and masked) and land in a stage that is
         // never multiplied; the TN loader's incremental row state needs strictly consecutive calls.
-        la.template load<AG>(kt_begin + 1, ra0, ma0);
-        lb.template load<BG>(kt_begin + 1, rb0, mb0);
+        la.template load<AG, FS>(kt_begin + 1, ra0, ma0);
+        lb.template load<BG, FS>(kt_begin + 1, rb0, mb0);
         for (int kt = kt_begin; kt < kt_end; kt += 2) {
-            la.template load<AG>(kt + 2, ra1, ma1);
-            lb.template load<BG>(kt + 2, rb1, mb1);
+            la.template load<AG, FS>(kt + 2, ra1, ma1);
+            lb.template load<BG, FS>(kt + 2, rb1, mb1);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMA phase
             compute(S0, S0 + Cfg::A_TILE);
             la.store(S1, ra0, ma0);
             lb.store(S1 + Cfg::A_TILE, rb0, mb0);
             __syncthreads();
             if (kt + 1 >= kt_end) break;
-            la.template load<AG>(kt + 3, ra0, ma0);
-            lb.template load<BG>(kt + 3, rb0, mb0);
+            la.template load<AG, FS>(kt + 3, ra0, ma0);
+            lb.template load<BG, FS>(kt + 3, rb0, mb0);
             __builtin_amdgcn_sched_barrier(0);
             compute(S1, S1 + Cfg::A_TILE);
             la.store(S0, ra1, ma1);
@@ -734,15 +740,24 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
             __syncthreads();
         }
     };
-    const bool ag = !TN && d.a.goff != nullptr, bg = !TN && d.b.goff != nullptr;
-    if (ag && bg)
-        run(std::true_type{}, std::true_type{});
-    else if (ag)
-        run(std::true_type{}, std::false_type{});
-    else if (bg)
-        run(std::false_type{}, std::true_type{});
-    else
-        run(std::false_type{}, std::false_type{});
+    if constexpr (TN) {
+        // the division-based 3-level row map (2x2 patch gathers) is a separate loop instance so the
+        // common running-address loader carries none of its code
+        if (la.fast && lb.fast)
+            run(std::false_type{}, std::false_type{}, std::true_type{});
+        else
+            run(std::false_type{}, std::false_type{}, std::false_type{});
+    } else {
+        const bool ag = d.a.goff != nullptr, bg = d.b.goff != nullptr;
+        if (ag && bg)
+            run(std::true_type{}, std::true_type{}, std::true_type{});
+        else if (ag)
+            run(std::true_type{}, std::false_type{}, std::true_type{});
+        else if (bg)
+            run(std::false_type{}, std::true_type{}, std::true_type{});
+        else
+            run(std::false_type{}, std::false_type{}, std::true_type{});
+    }
     if (p.vec_epi)
         store_tile_vec(d, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
     else
