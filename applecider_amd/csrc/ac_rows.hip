@@ -208,6 +208,149 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_reg_kernel(
     }
 }
 
+// Register-resident forward: one HBM read of the row (the 3-pass version re-read it through L1).
+template <int J>
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_reg_kernel(
+    const float *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ y, int64_t ldy, float *__restrict__ mean,
+    float *__restrict__ rstd, int64_t rows, int C, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (ROWS_BLOCK / 64);
+    const float invC = 1.0f / (float)C;
+    f32x4 g4[J], b4[J];
+    bool on[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = 4 * lane + 256 * j;
+        on[j] = c < C;
+        g4[j] = on[j] ? *(const f32x4 *)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[j] = on[j] ? *(const f32x4 *)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        f32x4 v[J];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            v[j] = on[j] ? *(const f32x4 *)(x + r * ldx + 4 * lane + 256 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mu = ac_wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = v[j][e] - mu;
+                    q += a * a;
+                }
+            }
+        }
+        const float rs = rsqrtf(ac_wave_sum(q) * invC + eps);
+        if (lane == 0) {
+            if (mean) mean[r] = mu;
+            if (rstd) rstd[r] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = (v[j][e] - mu) * rs * g4[j][e] + b4[j][e];
+                    o[e] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                }
+                *(f32x4 *)(y + r * ldy + 4 * lane + 256 * j) = o;
+            }
+        }
+    }
+}
+
+// Wide rows (1536 < C <= 3072, e.g. the 3072-channel last SpectraNet stage): a whole workgroup per
+// row, 3 float4 per thread, same register accumulation of dgamma / dbeta / column sums of dx.
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_wide_kernel(
+    const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
+    int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dxsum, int64_t rows, int C, int act) {
+    constexpr int J = 3;
+    __shared__ float red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float invC = 1.0f / (float)C;
+    f32x4 g4[J], b4[J], adg[J], adb[J], adx[J];
+    bool on[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = 4 * t + 1024 * j;
+        on[j] = c < C;
+        g4[j] = on[j] ? *(const f32x4 *)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[j] = (on[j] && beta) ? *(const f32x4 *)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float mu = mean[r], rs = rstd[r];
+        f32x4 xh[J], d[J];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+                const int c = 4 * t + 1024 * j;
+                xh[j] = *(const f32x4 *)(x + r * ldx + c);
+                d[j] = *(const f32x4 *)(dy + r * lddy + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h = (xh[j][e] - mu) * rs;
+                    float dd = d[j][e];
+                    if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                    xh[j][e] = h;
+                    d[j][e] = dd;
+                    const float g = dd * g4[j][e];
+                    s1 += g;
+                    s2 += g * h;
+                    adg[j][e] += dd * h;
+                    adb[j][e] += dd;
+                }
+            }
+        }
+        s1 = ac_wave_sum(s1);
+        s2 = ac_wave_sum(s2);
+        __syncthreads();  // previous row's partials consumed
+        if (lane == 0) {
+            red[0][wave] = s1;
+            red[1][wave] = s2;
+        }
+        __syncthreads();
+        const float c1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * invC;
+        const float c2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * invC;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (on[j]) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = rs * (d[j][e] * g4[j][e] - c1 - xh[j][e] * c2);
+                    adx[j][e] += o[e];
+                }
+                *(f32x4 *)(dx + r * lddx + 4 * t + 1024 * j) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (on[j]) {
+            const int c = 4 * t + 1024 * j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dgamma) atomicAdd(&dgamma[c + e], adg[j][e]);
+                if (dbeta) atomicAdd(&dbeta[c + e], adb[j][e]);
+                if (dxsum) atomicAdd(&dxsum[c + e], adx[j][e]);
+            }
+        }
+    }
+}
+
 // out[n] += sum_m x[m, n]: a workgroup owns a slab of rows and a 64-column strip; thread =
 // (column, one of 4 row phases) so that narrow matrices still use every lane; each wave reads
 // 256 contiguous bytes per row.
@@ -373,7 +516,18 @@ extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ac_aligned16(x) &&
                      ac_aligned16(y) && ac_aligned16(gamma) && ac_aligned16(beta);
     const int grid = grid_for_rows(rows, ROWS_BLOCK / 64, 256 * 16);
-    if (vec)
+    if (vec && C <= 1536) {
+        const int g2 = grid_for_rows(rows, 16, 2048);
+#define LN_FWD(JJ)                                                                             \
+    hipLaunchKernelGGL(layernorm_fwd_reg_kernel<JJ>, dim3(g2), dim3(ROWS_BLOCK), 0,           \
+                       (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, \
+                       eps, act)
+        if (C <= 256) LN_FWD(1);
+        else if (C <= 512) LN_FWD(2);
+        else if (C <= 768) LN_FWD(3);
+        else LN_FWD(6);
+#undef LN_FWD
+    } else if (vec)
         hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(grid), dim3(ROWS_BLOCK), 0,
                            (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C,
                            eps, act);
@@ -396,11 +550,17 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     if (C > 4096) return AC_EINVAL;  // 3*C floats of LDS
     if (rows == 0) return AC_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    const bool vec = (C % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) &&
-                     ac_aligned16(dy) && ac_aligned16(x) && ac_aligned16(dx) &&
-                     ac_aligned16(gamma) && (!beta || ac_aligned16(beta)) && C <= 1536;
+    const bool vec4 = (C % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) &&
+                      ac_aligned16(dy) && ac_aligned16(x) && ac_aligned16(dx) &&
+                      ac_aligned16(gamma) && (!beta || ac_aligned16(beta));
+    const bool vec = vec4 && C <= 1536;
     const size_t lds = 3 * (size_t)C * sizeof(float);
-    if (vec) {
+    if (vec4 && !vec && C <= 3072) {
+        int64_t g = rows < 2048 ? rows : 2048;
+        hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((int)g), dim3(ROWS_BLOCK), 0, stream, dy,
+                           lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, rows,
+                           C, act);
+    } else if (vec) {
         const int grid = grid_for_rows(rows, 16, 2048);
 #define LN_BWD(JJ)                                                                              \
     hipLaunchKernelGGL(layernorm_bwd_reg_kernel<JJ>, dim3(grid), dim3(ROWS_BLOCK), lds, stream, \
@@ -412,7 +572,7 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
         else LN_BWD(6);
 #undef LN_BWD
     } else {
-        if (dxsum) return AC_EINVAL;  // fused bias gradient only on the vector path
+        if (dxsum) return AC_EINVAL;  // fused bias gradient only on the vector paths
         const int grid = grid_for_rows(rows, 64, 1024);
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_BLOCK),
                            2 * (size_t)C * sizeof(float), stream, dy, lddy, x, ldx, mean, rstd,

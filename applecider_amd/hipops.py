@@ -913,7 +913,7 @@ class _ConvGroup1d(Function):
             ln_direct = gsink is not None and bsink is not None
             dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
             dbet = bsink if ln_direct else torch.zeros_like(ln_beta)
-            fuse_bias = Ncat % 4 == 0 and Ncat <= 1536
+            fuse_bias = Ncat % 4 == 0 and Ncat <= 3072
             bias_sums = torch.zeros(Ncat, device=dev, dtype=torch.float32) if fuse_bias else None
             _lib.check(_lib_().ac_layernorm_bwd(_p(dycat), Ncat, _p(ycat), Ncat, _p(mean), _p(rstd),
                                                 _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),

@@ -155,7 +155,7 @@ int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
  * nn.TransformerEncoderLayer; timm ConvNeXt block norm / LayerNorm2d in NHWC).
  * act = AC_ACT_GELU fuses the GELU of spectranet.py:35 (y = gelu(ln(x))).
  * bwd accumulates dgamma/dbeta with atomics: zero them first.  dxsum (nullable, C % 4 == 0 and
- * C <= 1536 only) additionally accumulates the column sums of dx, i.e. the bias gradient of the
+ * C <= 3072 only) additionally accumulates the column sums of dx, i.e. the bias gradient of the
  * conv/linear that produced x, so that no separate pass over dx is needed.
  * ---------------------------------------------------------------------- */
 int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
