@@ -199,6 +199,21 @@ def main():
                 "all_gemm": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                  "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
                              for k, v in gemms.items()}}
+    # HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
+    # (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    # this same command, FETCH_SIZE doubled for gfx950); None when the kernel is not in that file.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        want = {"gemm<TN>": "gemm_bf16in_kernel<true, 2, 2>", "gemm<NT>": "gemm_bf16in_kernel<false, 2, 2>",
+                "conv1d_window": "conv1d_window_kernel"}.get(dom_name)
+        if args.math == "bf16" and want:
+            for k, v in pmc.items():
+                if want in k:
+                    roofline["traffic"] = round(v["per_launch_MB"] * 1e6)
+                    roofline["traffic_unit"] = "bytes per launch (fabric-side FETCH+WRITE, PMC)"
+                    break
+    except Exception:
+        pass
     out = {
         "metric": "multimodal samples/sec/GPU (fwd+bwd) at batch 512; 1->8 GPU scaling",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",
