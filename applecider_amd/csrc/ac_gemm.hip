@@ -83,6 +83,28 @@ __device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (
     });
 }
 
+// Split-K epilogue: straight-line no-return float atomics (plain row-major C, alpha only).  The
+// general per-element epilogue costs ~25 us per 128x128 tile (branches around every element), more
+// than the K loop of a skinny weight-gradient product; this form leaves its 64 atomics per lane in
+// flight.  Each wave-instruction adds two 128-byte row segments (the full-rate shape).
+__device__ __forceinline__ void store_tile_atomic(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+                                                  int row_base, int col_base, int li, int lh) {
+    const int n0 = col_base + li, n1 = n0 + 32;
+    const bool v0 = n0 < d.N, v1 = n1 < d.N;
+    float *c = (float *)d.c.ptr + n0;
+    const int64_t ldc = d.c.rows.s3;
+    const float alpha = d.alpha;
+    static_for<0, 32>([&](auto idx) {
+        constexpr int sa = decltype(idx)::value / 16, e = decltype(idx)::value % 16;
+        const int m = row_base + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < d.M) {
+            float *cr = c + (int64_t)m * ldc;
+            if (v0) atomicAdd(cr, acc[sa][0][e] * alpha);
+            if (v1) atomicAdd(cr + 32, acc[sa][1][e] * alpha);
+        }
+    });
+}
+
 // 16-byte epilogue: the wave parks each 32x64 half of its accumulator tile in 8 KB of (now idle)
 // LDS and re-reads it row-major, so every lane handles 4 consecutive columns of one row: bias /
 // aux / residual come in as float4 and C goes out as float4 — 4x fewer memory instructions than the
@@ -318,7 +340,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    if (p.vec_epi)
+    if (p.vec_epi == 2)
+        store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    else if (p.vec_epi)
         store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
         store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
@@ -452,7 +476,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    if (p.vec_epi)
+    if (p.vec_epi == 2)
+        store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    else if (p.vec_epi)
         store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
         store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
@@ -758,7 +784,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
         else
             run(std::false_type{}, std::false_type{}, std::true_type{});
     }
-    if (p.vec_epi)
+    if (p.vec_epi == 2)
+        store_tile_atomic(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
+    else if (p.vec_epi)
         store_tile_vec(d, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
     else
         store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
@@ -872,7 +900,12 @@ bool rowmap_aligned(const ac_rowmap &r) {
 }
 
 int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
-    if (accumulate == 2 || (d.N % 4)) return 0;  // atomics keep the 128-byte-per-row lane layout
+    if (accumulate == 2) {  // atomics keep the 128-byte-per-row lane layout
+        const bool lean = !d.bias && !d.pre_out && !d.act && !d.dact && !d.colscale && !d.residual &&
+                          d.c.rows.r1 == 0 && !d.c.goff;
+        return lean ? 2 : 0;
+    }
+    if (d.N % 4) return 0;
     if (!ac_aligned16(d.c.ptr) || !rowmap_aligned(d.c.rows)) return 0;
     if (d.bias && !ac_aligned16(d.bias)) return 0;
     if (d.colscale && !ac_aligned16(d.colscale)) return 0;
@@ -908,6 +941,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         GemmParams p;
         p.d = d;
         if (d.split_k > 1) p.d.accumulate = 2;
+        if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
         p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
         // tile shape: force_tile (tests/tuning) or by output shape
@@ -949,6 +983,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         return AC_OK;
     }
     if (d.split_k > 1) p.d.accumulate = 2;
+    if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
     if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
     p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
     p.tiles_m = (d.M + BM - 1) / BM;

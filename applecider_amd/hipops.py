@@ -192,9 +192,16 @@ def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw
 
 
 def _split_for(m_out: int, n_out: int, k_red: int) -> int:
-    tiles = -(-m_out // 128) * -(-n_out // 128)
-    nkt = -(-k_red // 32)
-    return max(1, min(1024 // max(tiles, 1), nkt // 16))
+    """Split-K factor of a weight-gradient product (measured, tools/bench_split.py): long reductions
+    get >= 64 K tiles per workgroup and up to 4 workgroups per CU; skinny outputs that cannot fill
+    the chip that way are cut down to ~8 K tiles per workgroup, aiming at one workgroup per CU (each
+    extra workgroup pays a fixed prologue + atomic epilogue of a few microseconds)."""
+    tiles = max(1, -(-m_out // 128) * -(-n_out // 128))
+    nkt = -(-k_red // 64)
+    split = max(1, min(1024 // tiles, nkt // 64))
+    if tiles * split < 256:
+        split = max(1, min(256 // tiles, nkt // 8))
+    return split
 
 
 _seed_counter = itertools.count(1)
