@@ -41,6 +41,9 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p), ("pre_out", C.c_void_p), ("ld_pre", C.c_int64),
         ("aux", C.c_void_p), ("ld_aux", C.c_int64),
         ("colscale", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("c16", C.c_void_p), ("ld_c16", C.c_int64),
+        ("mask16", C.c_void_p), ("ld_mask16", C.c_int64),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
     ]
 
 
@@ -72,6 +75,7 @@ SIGNATURES = {
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ac_colsum_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "ac_act_fwd": [_P, _P, _I64, _I32, _P],
     "ac_copy2d": [_P, _I64, _P, _I64, _I64, _I32, _P],

@@ -35,6 +35,14 @@ struct GemmParams {
     int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
 };
 
+// round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
+__device__ __forceinline__ unsigned short epi_bf16(float x) {
+    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+}
+__device__ __forceinline__ float epi_bf16_to_f32(unsigned short h) {
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+
 __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int n, float acc,
                                                int64_t caddr) {
     float v = acc * d.alpha;
@@ -42,8 +50,14 @@ __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int
     if (d.pre_out) d.pre_out[(int64_t)m * d.ld_pre + n] = v;
     v = ac_act(v, d.act);
     if (d.dact) v *= ac_dact(d.aux[(int64_t)m * d.ld_aux + n], d.dact);
+    if (d.mask16) v = epi_bf16_to_f32(((const unsigned short *)d.mask16)[(int64_t)m * d.ld_mask16 + n]) > 0.f ? v : 0.f;
     if (d.colscale) v *= d.colscale[n];
+    if (d.drop_p > 0.f)
+        v = ac_rand01(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n) >= d.drop_p
+                ? v * (1.0f / (1.0f - d.drop_p)) : 0.f;
     if (d.residual) v += d.residual[(int64_t)m * d.ld_res + n];
+    if (d.c16) ((unsigned short *)d.c16)[(int64_t)m * d.ld_c16 + n] = epi_bf16(v);
+    if (!d.c.ptr) return;
     float *c = (float *)d.c.ptr + caddr;
     if (d.accumulate == 2)
         atomicAdd(c, v);
@@ -123,8 +137,27 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= ac_dact(a[j], d.dact);
     }
+    if (d.mask16) {
+        const ushort4 k = *(const ushort4 *)((const unsigned short *)d.mask16 + (int64_t)m * d.ld_mask16 + n);
+        v[0] = epi_bf16_to_f32(k.x) > 0.f ? v[0] : 0.f;
+        v[1] = epi_bf16_to_f32(k.y) > 0.f ? v[1] : 0.f;
+        v[2] = epi_bf16_to_f32(k.z) > 0.f ? v[2] : 0.f;
+        v[3] = epi_bf16_to_f32(k.w) > 0.f ? v[3] : 0.f;
+    }
     if (d.colscale) v *= *(const f32x4 *)(d.colscale + n);
+    if (d.drop_p > 0.f) {
+        const float inv_keep = 1.0f / (1.0f - d.drop_p);
+        const uint64_t i0 = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(d.drop_seed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
+    }
     if (d.residual) v += *(const f32x4 *)(d.residual + (int64_t)m * d.ld_res + n);
+    if (d.c16) {
+        ushort4 h;
+        h.x = epi_bf16(v[0]); h.y = epi_bf16(v[1]); h.z = epi_bf16(v[2]); h.w = epi_bf16(v[3]);
+        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + n) = h;
+    }
+    if (!d.c.ptr) return;
     f32x4 *c = (f32x4 *)((float *)d.c.ptr + caddr);
     if (d.accumulate == 1)
         *c += v;
@@ -138,22 +171,23 @@ __device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, const f32x
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = col_base + c4;
     const int64_t coff = n < d.N ? inner_off(d.c.goff, n) : 0;
-#pragma unroll
-    for (int sa = 0; sa < 2; ++sa) {
+    // compile-time indices into acc throughout: a loop the compiler declines to unroll would index
+    // the accumulators dynamically and push all 64 of them to scratch
+    static_for<0, 2>([&](auto sidx) {
+        constexpr int sa = decltype(sidx)::value;
         static_for<0, 16>([&](auto idx) {
             constexpr int e = decltype(idx)::value;
             const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
             wbuf[r * 64 + li] = acc[sa][0][e];
             wbuf[r * 64 + 32 + li] = acc[sa][1][e];
         });
-#pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int r = it * 4 + rsub;
             const f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4);
             const int m = row_base + sa * 32 + r;
             if (m < d.M && n < d.N) epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------
@@ -902,16 +936,18 @@ bool rowmap_aligned(const ac_rowmap &r) {
 int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
     if (accumulate == 2) {  // atomics keep the 128-byte-per-row lane layout
         const bool lean = !d.bias && !d.pre_out && !d.act && !d.dact && !d.colscale && !d.residual &&
-                          d.c.rows.r1 == 0 && !d.c.goff;
+                          !d.mask16 && !d.c16 && d.drop_p <= 0.f && d.c.rows.r1 == 0 && !d.c.goff;
         return lean ? 2 : 0;
     }
     if (d.N % 4) return 0;
-    if (!ac_aligned16(d.c.ptr) || !rowmap_aligned(d.c.rows)) return 0;
+    if (d.c.ptr && (!ac_aligned16(d.c.ptr) || !rowmap_aligned(d.c.rows))) return 0;
     if (d.bias && !ac_aligned16(d.bias)) return 0;
     if (d.colscale && !ac_aligned16(d.colscale)) return 0;
     if (d.pre_out && (!ac_aligned16(d.pre_out) || (d.ld_pre % 4))) return 0;
     if (d.aux && (!ac_aligned16(d.aux) || (d.ld_aux % 4))) return 0;
     if (d.residual && (!ac_aligned16(d.residual) || (d.ld_res % 4))) return 0;
+    if (d.c16 && (((uintptr_t)d.c16 & 7u) || (d.ld_c16 % 4))) return 0;
+    if (d.mask16 && (((uintptr_t)d.mask16 & 7u) || (d.ld_mask16 % 4))) return 0;
     return 1;  // c.goff entries are multiples of 4 by contract
 }
 
@@ -923,7 +959,11 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return AC_EINVAL;
     if (d.mode < 0 || d.mode > 2) return AC_EINVAL;
-    if (!d.a.ptr || !d.b.ptr || !d.c.ptr) return AC_EINVAL;
+    if (!d.a.ptr || !d.b.ptr || (!d.c.ptr && !d.c16)) return AC_EINVAL;
+    if (!d.c.ptr && (d.accumulate || d.split_k > 1)) return AC_EINVAL;  // bf16-only output: plain store
+    if (d.c16 && d.split_k > 1) return AC_EINVAL;
+    if (d.drop_p < 0.f || d.drop_p >= 1.f) return AC_EINVAL;
+    if ((d.drop_p > 0.f || d.mask16) && d.split_k > 1) return AC_EINVAL;
     if (d.dact && !d.aux) return AC_EINVAL;
     if (d.a.rows.r1 != 0 && d.a.rows.r2 == 0) return AC_EINVAL;
     if (d.b.rows.r1 != 0 && d.b.rows.r2 == 0) return AC_EINVAL;

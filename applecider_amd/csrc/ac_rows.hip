@@ -377,6 +377,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     if (ph == 0 && c < cols) atomicAdd(&out[c], (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
 }
 
+// bf16 input (the bf16 hidden gradient the fused MLP backward keeps): a lane owns a column PAIR
+// (one dword), a wave reads 256 contiguous bytes per row, fp32 sums.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short *__restrict__ x,
+                                                          int64_t ldx, float *__restrict__ out,
+                                                          int64_t rows, int cols, int rows_per_block) {
+    __shared__ float part[4][128];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 128 + 2 * cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (c < cols) {
+        int64_t r = r0 + ph;
+        for (; r + 4 < r1; r += 8) {
+            const unsigned u = *(const unsigned *)(x + r * ldx + c);
+            const unsigned w = *(const unsigned *)(x + (r + 4) * ldx + c);
+            a0 += __builtin_bit_cast(float, u << 16);
+            a1 += __builtin_bit_cast(float, u & 0xffff0000u);
+            b0 += __builtin_bit_cast(float, w << 16);
+            b1 += __builtin_bit_cast(float, w & 0xffff0000u);
+        }
+        if (r < r1) {
+            const unsigned u = *(const unsigned *)(x + r * ldx + c);
+            a0 += __builtin_bit_cast(float, u << 16);
+            a1 += __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+    }
+    part[ph][2 * cl] = a0 + b0;
+    part[ph][2 * cl + 1] = a1 + b1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.y * 128 + threadIdx.x;
+        if (cc < cols)
+            atomicAdd(&out[cc], (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                    (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    }
+}
+
 __global__ __launch_bounds__(ROWS_BLOCK) void l2norm_fwd_kernel(const float *__restrict__ x,
                                                                 float *__restrict__ y,
                                                                 float *__restrict__ norm,
@@ -595,6 +634,24 @@ extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, 
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows,
                        cols, rpb);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_colsum_bf16(const void *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
+                              int32_t accumulate, ac_stream_t stream) {
+    if (!x || !out || rows < 0 || cols <= 0) return AC_EINVAL;
+    if ((cols & 1) || (ldx & 1) || ((uintptr_t)x & 3u)) return AC_EALIGN;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    if (rows == 0) return AC_OK;
+    int rpb = 256;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 127) / 128));
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)x, ldx, out, rows, cols, rpb);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

@@ -66,7 +66,8 @@ def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) 
 
 def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
          ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
-         accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0):
+         accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0, c16=None, ld_c16=0,
+         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0):
     d = GemmDesc()
     d.mode, d.math = mode, (_MATH if math is None else math)
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -78,6 +79,9 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     d.aux, d.ld_aux = _p(aux), ld_aux
     d.colscale = _p(colscale)
     d.residual, d.ld_res = _p(residual), ld_res
+    d.c16, d.ld_c16 = _p(c16), ld_c16
+    d.mask16, d.ld_mask16 = _p(mask16), ld_mask16
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     _lib.check(_lib_().ac_gemm(C.byref(d), _stream()), "ac_gemm")
 
 
@@ -319,6 +323,151 @@ class _Linear(Function):
                 db = colsum(_p(g), N, M, N, dy.device)
         dres = dy if ctx.has_res else None
         return dx, dw, db, None, dres, dcs
+
+
+class _MLP(Function):
+    """y = [drop2](fc2(drop1(act(fc1(x))))) [* colscale] [+ residual] with the hidden activation kept
+    in bf16 only (bf16 math mode).  ConvNeXt block MLP (timm convnext_tiny, astrominn.py:12-17:
+    act = GELU, colscale = layer-scale gamma, residual = block input) and the encoder feed-forward
+    (Time2Vec.py:96-101: act = ReLU, dropout on the hidden and on the output).
+
+    HBM traffic of the 4C-wide hidden per row, forward + backward: 88 B per hidden element pair
+    instead of 192 (the fp32 activation, its cast pass, the separate act-backward pass and the fp32
+    hidden gradient are gone).  GELU keeps the fp32 pre-activation for act'; ReLU (+dropout) needs
+    nothing but the bf16 output itself, which is its own backward mask."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p1, p2, residual, colscale):
+        x = _chk(x, "x")
+        Hd, K = w1.shape
+        N = w2.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        dev = x.device
+        if act not in (ACT_GELU, ACT_RELU):
+            raise ValueError("fused MLP supports GELU and ReLU")
+        seed1 = next_seed() if p1 > 0 else 0
+        seed2 = next_seed() if p2 > 0 else 0
+        x16, w1_16, w2_16 = cast16(x2), cast16_w(w1), cast16_w(w2)
+        need_grad = any(ctx.needs_input_grad)
+        pre1 = torch.empty(M, Hd, device=dev, dtype=torch.float32) if (act == ACT_GELU and need_grad) else None
+        g16 = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+        gemm(AC_GEMM_NT, M, Hd, K, mat(_p(x16), K), mat(_p(w1_16), K), mat(None, Hd), bias=b1, act=act,
+             pre_out=pre1, ld_pre=Hd, c16=g16, ld_c16=Hd, drop_p=p1, drop_seed=seed1,
+             math=_lib.MATH_BF16_IN)
+        y = torch.empty(M, N, device=dev, dtype=torch.float32)
+        pre2 = torch.empty_like(y) if (colscale is not None and need_grad) else None
+        res2 = _chk(residual, "residual").reshape(M, N) if residual is not None else None
+        gemm(AC_GEMM_NT, M, N, Hd, mat(_p(g16), Hd), mat(_p(w2_16), Hd), mat(_p(y), N), bias=b2,
+             pre_out=pre2, ld_pre=N, colscale=colscale, drop_p=p2, drop_seed=seed2, residual=res2,
+             ld_res=N, math=_lib.MATH_BF16_IN)
+        ctx.save_for_backward(x16, w1, w2, pre1, g16, pre2, colscale)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.act, ctx.p1, ctx.p2, ctx.seed1, ctx.seed2 = act, p1, p2, seed1, seed2
+        ctx.shape_x, ctx.has_res = x.shape, residual is not None
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w1, w2, pre1, g16, pre2, colscale = ctx.saved_tensors
+        w1p, b1p, w2p, b2p = ctx.params
+        Hd, K = w1.shape
+        N = w2.shape[0]
+        M = x16.shape[0]
+        dev = dy.device
+        dy2 = _chk(dy, "dy").reshape(M, N)
+        lib, st = _lib_(), _stream()
+        # ---- through dropout2 / layer scale to the gradient of fc2's linear output
+        g2 = dy2
+        if ctx.p2 > 0:
+            g2 = torch.empty_like(dy2)
+            _lib.check(lib.ac_dropout(_p(dy2), _p(g2), M * N, ctx.p2, ctx.seed2, 0, st), "ac_dropout")
+        dcs = None
+        if colscale is not None:
+            src, g2 = g2, torch.empty_like(dy2)
+            dcs = torch.zeros_like(colscale)
+            _lib.check(lib.ac_layerscale_bwd(_p(src), _p(pre2), _p(colscale), _p(g2), _p(dcs), M, N, st),
+                       "ac_layerscale_bwd")
+        g2_16 = cast16(g2)
+        db2 = _bias_grad(b2p, g2, M, N, ctx.needs_input_grad[4])
+        # ---- dW2 = g2^T @ hidden
+        dw2 = _weight_grad(w2p, g2_16, N, g16, Hd, M, ctx.needs_input_grad[3])
+        # ---- hidden gradient, bf16 only: (g2 @ W2) * act'(.) [* dropout1 mask]
+        dh16 = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+        w2T16 = cast16_wT(w2p if w2p.shape == w2.shape else w2)
+        if ctx.act == ACT_GELU:
+            gemm(AC_GEMM_NT, M, Hd, N, mat(_p(g2_16), N), mat(_p(w2T16), N), mat(None, Hd),
+                 dact=ACT_GELU, aux=pre1, ld_aux=Hd, c16=dh16, ld_c16=Hd, math=_lib.MATH_BF16_IN)
+        else:
+            gemm(AC_GEMM_NT, M, Hd, N, mat(_p(g2_16), N), mat(_p(w2T16), N), mat(None, Hd),
+                 mask16=g16, ld_mask16=Hd, alpha=1.0 / (1.0 - ctx.p1) if ctx.p1 > 0 else 1.0,
+                 c16=dh16, ld_c16=Hd, math=_lib.MATH_BF16_IN)
+        db1 = None
+        if b1p is not None and ctx.needs_input_grad[2]:
+            sink = _sink(b1p)
+            out = sink if sink is not None else torch.zeros(Hd, device=dev, dtype=torch.float32)
+            _lib.check(lib.ac_colsum_bf16(_p(dh16), Hd, _p(out), M, Hd, 1, st), "ac_colsum_bf16")
+            if sink is not None:
+                _grad_written(b1p)
+            else:
+                db1 = out
+        dw1 = _weight_grad(w1p, dh16, Hd, x16, K, M, ctx.needs_input_grad[1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+            w1T16 = cast16_wT(w1p if w1p.shape == w1.shape else w1)
+            gemm(AC_GEMM_NT, M, K, Hd, mat(_p(dh16), Hd), mat(_p(w1T16), Hd), mat(_p(dx), K),
+                 math=_lib.MATH_BF16_IN)
+            dx = dx.reshape(ctx.shape_x)
+        dres = dy if ctx.has_res else None
+        return dx, dw1, db1, dw2, db2, None, None, None, dres, dcs
+
+
+def _bias_grad(bp, g, M, N, needed):
+    """colsum of an fp32 gradient into the parameter's sink (or a fresh tensor)."""
+    if bp is None or not needed:
+        return None
+    sink = _sink(bp)
+    if sink is not None:
+        _lib.check(_lib_().ac_colsum(_p(g), N, _p(sink), M, N, 1, _stream()), "ac_colsum")
+        _grad_written(bp)
+        return None
+    return colsum(_p(g), N, M, N, g.device)
+
+
+def _weight_grad(wp, g16, N, a16, K, M, needed):
+    """dW[N, K] = g16[M, N]^T @ a16[M, K] (bf16 operands) into the parameter's sink."""
+    if not needed:
+        return None
+    sink = _sink(wp)
+    dw = sink if sink is not None else torch.zeros(N, K, device=g16.device, dtype=torch.float32)
+    gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(a16), K), mat(_p(dw), K), accumulate=2,
+         split_k=_split_for(N, K, M), math=_lib.MATH_BF16_IN)
+    if sink is not None:
+        _grad_written(wp)
+        return None
+    return dw
+
+
+def mlp(x, w1, b1, w2, b2, act, p1=0.0, p2=0.0, training=True, residual=None, colscale=None):
+    """Two-layer perceptron.  bf16 math mode with 8-aligned widths runs the fused bf16-hidden path;
+    otherwise the two Linear products with their separate dropout / residual kernels."""
+    act_code = ACT_CODES[act] if not isinstance(act, int) else act
+    if not training:
+        p1 = p2 = 0.0
+    Hd, K = w1.shape
+    N = w2.shape[0]
+    M = x.numel() // K
+    if (bf16_operands() and K % 8 == 0 and Hd % 8 == 0 and N % 8 == 0 and _big(M, Hd, K)
+            and _big(M, N, Hd) and act_code in (ACT_GELU, ACT_RELU) and x.is_cuda):
+        return _MLP.apply(x, w1, b1, w2, b2, act_code, float(p1), float(p2), residual, colscale)
+    h = linear(x, w1, b1, act=act_code)
+    if p1 > 0:
+        h = dropout(h, p1, True)
+    if p2 > 0:
+        y = dropout(linear(h, w2, b2, colscale=colscale), p2, True)
+        return add(residual, y) if residual is not None else y
+    return linear(h, w2, b2, residual=residual, colscale=colscale)
 
 
 def linear(x, w, b=None, act=None, residual=None, colscale=None):

@@ -90,11 +90,9 @@ class EncoderLayer(nn.Module):
         else:
             x = sa.out_proj(a, residual=x)
         x = self.norm1(x)
-        h = self.linear1(x, act="relu")
-        if drop:
-            x = H.add(x, H.dropout(self.linear2(H.dropout(h, self.p, True)), self.p, True))
-        else:
-            x = self.linear2(h, residual=x)
+        l1, l2 = self.linear1, self.linear2
+        x = H.mlp(x, l1.weight, l1.bias, l2.weight, l2.bias, "relu", p1=self.p, p2=self.p,
+                  training=self.training, residual=x)
         return self.norm2(x)
 
 

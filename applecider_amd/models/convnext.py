@@ -50,8 +50,9 @@ class ConvNeXtBlock(nn.Module):
     def forward(self, x):  # x: [B, H, W, C]
         h = self.conv_dw(x)
         h = self.norm(h)
-        h = self.mlp.fc1(h, act="gelu")
-        return self.mlp.fc2(h, residual=x, colscale=self.gamma)
+        m = self.mlp
+        return H.mlp(h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu", residual=x,
+                     colscale=self.gamma)
 
 
 class Downsample(nn.Sequential):

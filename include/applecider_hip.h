@@ -68,9 +68,15 @@ const char *ac_strerror(int code);
  *
  * Epilogue, per element, in this order:
  *   v = alpha*acc (+ bias[n]); if pre_out: pre_out[m,n] = v; v = act(v);
- *   if dact: v *= act'(aux[m,n]); if colscale: v *= colscale[n];
+ *   if dact: v *= act'(aux[m,n]); if mask16: v = mask16[m,n] > 0 ? v : 0;
+ *   if colscale: v *= colscale[n];
+ *   if drop_p > 0: v = keep(drop_seed, m*N + n) ? v/(1-drop_p) : 0   (ac_dropout's generator);
  *   if residual: v += residual[m,n];
+ *   if c16: c16[m,n] = bf16(v)  (row-major, ld_c16; c.ptr may then be NULL: bf16-only output);
  *   accumulate: 0 store, 1 C += v, 2 atomicAdd(C, v)  (2 is forced by split_k > 1).
+ * mask16 is a bf16 matrix: with act = RELU (and dropout) in the forward product, the forward's bf16
+ * output is its own backward mask — alpha = 1/(1-p) then rebuilds dropout's scale
+ * (Time2Vec.py:96-101 feed-forward: linear2(dropout(relu(linear1(x))))).
  * ---------------------------------------------------------------------- */
 enum { AC_GEMM_NT = 0, AC_GEMM_NN = 1, AC_GEMM_TN = 2 };
 enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC_ACT_TANH = 4 };
@@ -113,6 +119,12 @@ typedef struct ac_gemm_desc {
     const float *colscale;
     const float *residual;
     int64_t ld_res;
+    void *c16;            /* nullable: bf16 copy of the output, row-major */
+    int64_t ld_c16;
+    const void *mask16;   /* nullable: bf16 matrix, v is zeroed where mask16[m,n] <= 0 */
+    int64_t ld_mask16;
+    float drop_p;         /* 0: no dropout */
+    uint64_t drop_seed;
 } ac_gemm_desc;
 
 int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
@@ -172,6 +184,9 @@ int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
 /* out[n] (+)= sum_m x[m,n]  — bias gradients. */
 int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
               int32_t accumulate, ac_stream_t stream);
+/* The same for a bf16 matrix (cols and ldx even): bias gradient of a bf16 hidden gradient. */
+int ac_colsum_bf16(const void *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
+                   int32_t accumulate, ac_stream_t stream);
 /* out = dy * act'(aux)  (kinds as in ac_gemm dact); in-place allowed. */
 int ac_act_bwd(const float *dy, const float *aux, float *out, int64_t n, int32_t kind,
                ac_stream_t stream);

@@ -640,3 +640,82 @@ def test_linear_and_patchconv_bf16(dev, bf16_mode):
     close(yd.permute(0, 3, 1, 2), y, tol=1e-4, name="y")
     close(xd.grad.permute(0, 3, 1, 2), x.grad, tol=1e-4, name="dx")
     close(wd.grad.reshape(Co, 2, 2, C).permute(0, 3, 1, 2), w.grad, tol=1e-4, name="dw")
+
+
+# ----------------------------------------------------------------------------- fused bf16-hidden MLP
+def test_mlp_bf16_gelu_layerscale(dev, bf16_mode):
+    """ConvNeXt block MLP (GELU, layer scale, residual) with the hidden kept in bf16 only, against a
+    torch restatement that rounds at the same points (operands, hidden activation, hidden gradient)."""
+    from applecider_amd import hipops as H
+    rb = lambda t: t.bfloat16().float()
+    M, Cn, Hd = 900, 96, 384
+    x = rb(g(dev, M, Cn, seed=1))
+    w1, b1 = rb(g(dev, Hd, Cn, seed=2) / 10), g(dev, Hd, seed=3)
+    w2, b2 = rb(g(dev, Cn, Hd, seed=4) / 20), g(dev, Cn, seed=5)
+    gamma, res = g(dev, Cn, seed=6), g(dev, M, Cn, seed=7)
+    dy = g(dev, M, Cn, seed=8)
+    h = x @ w1.t() + b1
+    g16 = rb(F.gelu(h))
+    ylin = g16 @ w2.t() + b2
+    y = ylin * gamma + res
+    g2 = dy * gamma
+    g2_16 = rb(g2)
+    hh = h.clone().requires_grad_()
+    F.gelu(hh).sum().backward()
+    dh = rb((g2_16 @ w2) * hh.grad)
+    ref = {"dx": dh @ w1, "dw1": dh.t() @ x, "db1": dh.sum(0), "dw2": g2_16.t() @ g16, "db2": g2.sum(0),
+           "dgamma": (dy * ylin).sum(0)}
+    t = lambda a: a.detach().to(dev).requires_grad_()
+    xd, w1d, b1d, w2d, b2d, gd, rd = (t(a) for a in (x, w1, b1, w2, b2, gamma, res))
+    yd = H.mlp(xd, w1d, b1d, w2d, b2d, "gelu", residual=rd, colscale=gd)
+    yd.backward(dy.to(dev))
+    close(yd, y, tol=1e-3, name="y")          # a near-tie bf16 rounding of one hidden value may flip
+    close(rd.grad, dy, tol=0, name="dres")
+    for name, got in (("dx", xd.grad), ("dw1", w1d.grad), ("db1", b1d.grad), ("dw2", w2d.grad),
+                      ("db2", b2d.grad), ("dgamma", gd.grad)):
+        close(got, ref[name], tol=3e-3, name=name)
+
+
+def test_mlp_bf16_relu_dropout_matches_unfused(dev, bf16_mode):
+    """Encoder feed-forward with both dropouts fused into the GEMM epilogues against the unfused
+    kernels (Linear, Dropout, Add) drawing the same seeds: same masks, same bf16 roundings."""
+    import itertools
+    from applecider_amd import hipops as H
+    M, Cn, Hd, p = 1290, 128, 512, 0.4
+    x, res_same = g(dev, M, Cn, seed=1), True
+    w1, b1 = g(dev, Hd, Cn, seed=2) / 10, g(dev, Hd, seed=3)
+    w2, b2 = g(dev, Cn, Hd, seed=4) / 20, g(dev, Cn, seed=5)
+    dy = g(dev, M, Cn, seed=8).to(dev)
+    t = lambda a: a.detach().to(dev).requires_grad_()
+
+    def run(fused):
+        H._seed_counter = itertools.count(5000)
+        xd, w1d, b1d, w2d, b2d = (t(a) for a in (x, w1, b1, w2, b2))
+        if fused:
+            y = H.mlp(xd, w1d, b1d, w2d, b2d, "relu", p1=p, p2=p, training=True, residual=xd)
+        else:
+            hd = H.dropout(H.linear(xd, w1d, b1d, act="relu"), p, True)
+            y = H.add(xd, H.dropout(H.linear(hd, w2d, b2d), p, True))
+        y.backward(dy)
+        return [y.detach()] + [a.grad for a in (xd, w1d, b1d, w2d, b2d)]
+
+    a, b = run(True), run(False)
+    zeros = float((a[0] - x.to(dev) == 0).float().mean())
+    assert 0.3 < zeros < 0.5, zeros                     # dropout2 really dropped ~p of the update
+    for name, u, v, tol in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), a, b,
+                               (1e-5, 5e-4, 5e-4, 5e-3, 1e-5, 1e-5)  # db1: summed from the bf16 hidden gradient):
+        close(u, v, tol=tol, name=name)
+    # eval mode: no dropout, still the fused path
+    xd, w1d, b1d, w2d, b2d = (t(a_) for a_ in (x, w1, b1, w2, b2))
+    ye = H.mlp(xd, w1d, b1d, w2d, b2d, "relu", p1=p, p2=p, training=False, residual=xd)
+    rb = lambda t_: t_.bfloat16().float()
+    ref = x + rb(F.relu(rb(x) @ rb(w1).t() + b1)) @ rb(w2).t() + b2
+    close(ye, ref, tol=5e-4, name="eval")   # near-tie bf16 roundings of the hidden may flip
+
+
+def test_colsum_bf16(dev):
+    from applecider_amd import hipops as H
+    x = g(dev, 1000, 386, seed=3).bfloat16().to(dev)
+    out = torch.zeros(386, device=dev)
+    H._lib.check(H._lib_().ac_colsum_bf16(H._p(x), 386, H._p(out), 1000, 386, 0, H._stream()), "colsum")
+    close(out, x.float().sum(0), tol=1e-5, name="colsum_bf16")
