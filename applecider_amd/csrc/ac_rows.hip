@@ -267,6 +267,196 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_reg_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sub-wave rows: a row of C = 4*G*J floats is owned by a GROUP of G lanes (G = 8..64), so a wave
+// works on 64/G rows at once and every lane carries J float4 — narrow rows (C = 64: one wave per
+// row used 16 of its 64 lanes and moved 256 B per load instruction) now keep all lanes and
+// 1 KB per instruction in flight.  Reductions stay inside the group (xor-shuffles below G).
+// The forward can also emit the bf16 copy the next matrix product reads (saves a cast pass).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float ac_group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned short ln_bf16(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return (unsigned short)(u >> 16);
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_sub_kernel(
+    const float *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ y, int64_t ldy,
+    unsigned short *__restrict__ y16, int64_t ldy16, float *__restrict__ mean,
+    float *__restrict__ rstd, int64_t rows, float eps, int act) {
+    constexpr int RPW = 64 / G, C = 4 * G * J;
+    const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
+    const int64_t r0 = ((int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6)) * RPW + slot;
+    const int64_t rstep = (int64_t)gridDim.x * (ROWS_BLOCK / 64) * RPW;
+    const float invC = 1.0f / (float)C;
+    f32x4 g4[J], b4[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        g4[j] = *(const f32x4 *)(gamma + 4 * (sub + G * j));
+        b4[j] = *(const f32x4 *)(beta + 4 * (sub + G * j));
+    }
+    for (int64_t r = r0; r < rows; r += rstep) {
+        f32x4 v[J];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            v[j] = *(const f32x4 *)(x + r * ldx + 4 * (sub + G * j));
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mu = ac_group_sum<G>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = v[j][e] - mu;
+                q += a * a;
+            }
+        }
+        const float rs = rsqrtf(ac_group_sum<G>(q) * invC + eps);
+        if (sub == 0) {
+            if (mean) mean[r] = mu;
+            if (rstd) rstd[r] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (v[j][e] - mu) * rs * g4[j][e] + b4[j][e];
+                o[e] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+            }
+            if (y) *(f32x4 *)(y + r * ldy + 4 * (sub + G * j)) = o;
+            if (y16) {
+                ushort4 h;
+                h.x = ln_bf16(o[0]); h.y = ln_bf16(o[1]); h.z = ln_bf16(o[2]); h.w = ln_bf16(o[3]);
+                *(ushort4 *)(y16 + r * ldy16 + 4 * (sub + G * j)) = h;
+            }
+        }
+    }
+}
+
+template <int G, int J>
+__global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
+    const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
+    int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dxsum, int64_t rows, int act) {
+    constexpr int RPW = 64 / G, C = 4 * G * J;
+    __shared__ __attribute__((aligned(16))) float sacc[3 * C];
+    const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
+    const int64_t r0 = ((int64_t)blockIdx.x * (ROWS_BLOCK / 64) + (threadIdx.x >> 6)) * RPW + slot;
+    const int64_t rstep = (int64_t)gridDim.x * (ROWS_BLOCK / 64) * RPW;
+    const float invC = 1.0f / (float)C;
+    f32x4 g4[J], b4[J], adg[J], adb[J], adx[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        g4[j] = *(const f32x4 *)(gamma + 4 * (sub + G * j));
+        b4[j] = beta ? *(const f32x4 *)(beta + 4 * (sub + G * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = threadIdx.x; c < 3 * C; c += ROWS_BLOCK) sacc[c] = 0.f;
+    for (int64_t r = r0; r < rows; r += rstep) {
+        const float mu = mean[r], rs = rstd[r];
+        f32x4 xh[J], d[J];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            xh[j] = *(const f32x4 *)(x + r * ldx + 4 * (sub + G * j));
+            d[j] = *(const f32x4 *)(dy + r * lddy + 4 * (sub + G * j));
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (xh[j][e] - mu) * rs;
+                float dd = d[j][e];
+                if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                xh[j][e] = h;
+                d[j][e] = dd;
+                const float g = dd * g4[j][e];
+                s1 += g;
+                s2 += g * h;
+                adg[j][e] += dd * h;
+                adb[j][e] += dd;
+            }
+        }
+        const float c1 = ac_group_sum<G>(s1) * invC;
+        const float c2 = ac_group_sum<G>(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = rs * (d[j][e] * g4[j][e] - c1 - xh[j][e] * c2);
+                adx[j][e] += o[e];
+            }
+            *(f32x4 *)(dx + r * lddx + 4 * (sub + G * j)) = o;
+        }
+    }
+    // the 64/G row slots of a wave hold partial sums of the same channels: fold them with
+    // shuffles first so that only one lane per channel touches LDS
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) {
+                adg[j][e] += __shfl_xor(adg[j][e], o, 64);
+                adb[j][e] += __shfl_xor(adb[j][e], o, 64);
+                adx[j][e] += __shfl_xor(adx[j][e], o, 64);
+            }
+        }
+    }
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int c = 4 * (sub + G * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&sacc[c + e], adg[j][e]);
+                atomicAdd(&sacc[C + c + e], adb[j][e]);
+                if (dxsum) atomicAdd(&sacc[2 * C + c + e], adx[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += ROWS_BLOCK) {
+        if (dgamma) atomicAdd(&dgamma[c], sacc[c]);
+        if (dbeta) atomicAdd(&dbeta[c], sacc[C + c]);
+        if (dxsum) atomicAdd(&dxsum[c], sacc[2 * C + c]);
+    }
+}
+
+// (G, J) with 4*G*J == C, or 0 when no exact sub-wave shape exists
+inline bool ln_sub_shape(int C, int *G, int *J) {
+    if (C % 4) return false;
+    const int V = C / 4;
+    const int gs[4] = {64, 32, 16, 8};
+    for (int i = 0; i < 4; ++i) {
+        if (V % gs[i] == 0) {
+            const int j = V / gs[i];
+            if (j == 1 || j == 2 || j == 3 || j == 6) {
+                *G = gs[i];
+                *J = j;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
 // Wide rows (1536 < C <= 3072, e.g. the 3072-channel last SpectraNet stage): a whole workgroup per
 // row, 3 float4 per thread, same register accumulation of dgamma / dbeta / column sums of dx.
 __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_wide_kernel(
@@ -545,15 +735,33 @@ inline int grid_for_rows(int64_t rows, int rows_per_block, int cap) {
 
 }  // namespace
 
+#define LN_SUB_CASES(X) \
+    X(64, 1) X(64, 2) X(64, 3) X(64, 6) X(32, 1) X(32, 3) X(16, 1) X(16, 3) X(8, 3) X(8, 1)
+
 extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
                                 const float *beta, float *y, int64_t ldy, float *mean,
                                 float *rstd, int64_t rows, int32_t C, float eps, int32_t act,
-                                ac_stream_t stream) {
-    if (!x || !gamma || !beta || !y || rows < 0 || C <= 0) return AC_EINVAL;
+                                void *y16, int64_t ldy16, ac_stream_t stream) {
+    if (!x || !gamma || !beta || (!y && !y16) || rows < 0 || C <= 0) return AC_EINVAL;
     if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
     if (rows == 0) return AC_OK;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ac_aligned16(x) &&
                      ac_aligned16(y) && ac_aligned16(gamma) && ac_aligned16(beta);
+    int G = 0, J = 0;
+    const bool sub = vec && ln_sub_shape(C, &G, &J) && (!y16 || (((uintptr_t)y16 & 7u) == 0 && ldy16 % 4 == 0));
+    if (sub) {
+        const int g2 = grid_for_rows(rows, 4 * (64 / G) * 2, 2048);
+#define LN_FWD_SUB(GG, JJ)                                                                        \
+    if (G == GG && J == JJ)                                                                       \
+        hipLaunchKernelGGL((layernorm_fwd_sub_kernel<GG, JJ>), dim3(g2), dim3(ROWS_BLOCK), 0,    \
+                           (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,                      \
+                           (unsigned short *)y16, ldy16, mean, rstd, rows, eps, act);
+        LN_SUB_CASES(LN_FWD_SUB)
+#undef LN_FWD_SUB
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
+    if (y16 || !y) return AC_EALIGN;  // the bf16 side output exists on the sub-wave path only
     const int grid = grid_for_rows(rows, ROWS_BLOCK / 64, 256 * 16);
     if (vec && C <= 1536) {
         const int g2 = grid_for_rows(rows, 16, 2048);
@@ -594,6 +802,19 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
                       ac_aligned16(gamma) && (!beta || ac_aligned16(beta));
     const bool vec = vec4 && C <= 1536;
     const size_t lds = 3 * (size_t)C * sizeof(float);
+    int G = 0, J = 0;
+    if (vec4 && ln_sub_shape(C, &G, &J)) {
+        const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 2048);
+#define LN_BWD_SUB(GG, JJ)                                                                       \
+    if (G == GG && J == JJ)                                                                      \
+        hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ>), dim3(grid), dim3(ROWS_BLOCK), 0, \
+                           stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma,  \
+                           dbeta, dxsum, rows, act);
+        LN_SUB_CASES(LN_BWD_SUB)
+#undef LN_BWD_SUB
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
     if (vec4 && !vec && C <= 3072) {
         int64_t g = rows < 2048 ? rows : 2048;
         hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((int)g), dim3(ROWS_BLOCK), 0, stream, dy,

@@ -90,6 +90,32 @@ def bf16_operands() -> bool:
     return _MATH == _lib.MATH_BF16
 
 
+def _ln_sub_shape(C: int) -> bool:
+    """Row widths the sub-wave LayerNorm kernels cover (ac_rows.hip ln_sub_shape)."""
+    if C % 4:
+        return False
+    V = C // 4
+    for g in (64, 32, 16, 8):
+        if V % g == 0:
+            return V // g in (1, 2, 3, 6)
+    return False
+
+
+def _side16_alloc(shape, C: int, device):
+    """bf16 side output of a producer kernel (bf16 math mode only)."""
+    if not bf16_operands() or not _ln_sub_shape(C):
+        return None
+    return torch.empty(shape, device=device, dtype=torch.bfloat16)
+
+
+def cast16_act(x: torch.Tensor, K: int) -> torch.Tensor:
+    """[rows, K] bf16 copy of an activation: the producer's side output when it left one."""
+    side = getattr(x, "_ac16", None)
+    if side is not None and side.shape == x.shape:
+        return side.reshape(-1, K)
+    return cast16(x.reshape(-1, K))
+
+
 def cast16(t: torch.Tensor) -> torch.Tensor:
     y = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
     _lib.check(_lib_().ac_cast_bf16(_p(t), _p(y), t.numel(), _stream()), "ac_cast_bf16")
@@ -258,7 +284,7 @@ class _Linear(Function):
         ctx.b16 = bf16_operands() and K % 8 == 0 and N % 8 == 0 and _big(M, N, K)
         x16 = None
         if ctx.b16:
-            x16, w16 = cast16(x2), cast16_w(w)
+            x16, w16 = cast16_act(x, K), cast16_w(w)
             gemm(AC_GEMM_NT, M, N, K, mat(_p(x16), K), mat(_p(w16), K), mat(_p(y), N), bias=b,
                  act=act, pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
                  math=_lib.MATH_BF16_IN)
@@ -348,7 +374,7 @@ class _MLP(Function):
             raise ValueError("fused MLP supports GELU and ReLU")
         seed1 = next_seed() if p1 > 0 else 0
         seed2 = next_seed() if p2 > 0 else 0
-        x16, w1_16, w2_16 = cast16(x2), cast16_w(w1), cast16_w(w2)
+        x16, w1_16, w2_16 = cast16_act(x, K), cast16_w(w1), cast16_w(w2)
         need_grad = any(ctx.needs_input_grad)
         pre1 = torch.empty(M, Hd, device=dev, dtype=torch.float32) if (act == ACT_GELU and need_grad) else None
         g16 = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
@@ -485,9 +511,12 @@ class _LayerNorm(Function):
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        y16 = _side16_alloc(x.shape, Cn, x.device)
         _lib.check(_lib_().ac_layernorm_fwd(_p(x), Cn, _p(gamma), _p(beta), _p(y), Cn, _p(mean),
-                                            _p(rstd), rows, Cn, eps, act, _stream()),
+                                            _p(rstd), rows, Cn, eps, act, _p(y16), Cn, _stream()),
                    "ac_layernorm_fwd")
+        if y16 is not None:
+            y._ac16 = y16   # the matrix product that consumes y reads this instead of casting
         ctx.act = act
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.gp, ctx.bp = gamma, beta
@@ -1043,9 +1072,12 @@ class _ConvGroup1d(Function):
             y = torch.empty_like(ycat)
             mean = torch.empty(rows, device=dev, dtype=torch.float32)
             rstd = torch.empty(rows, device=dev, dtype=torch.float32)
+            y16 = _side16_alloc(ycat.shape, Ncat, dev)
             _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), _p(y), Ncat,
                                                 _p(mean), _p(rstd), rows, Ncat, ln_eps, ACT_GELU,
-                                                _stream()), "ac_layernorm_fwd")
+                                                _p(y16), Ncat, _stream()), "ac_layernorm_fwd")
+            if y16 is not None:
+                y._ac16 = y16
             ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta)
             return y
         ctx.save_for_backward(xpad, *ws)

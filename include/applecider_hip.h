@@ -172,7 +172,9 @@ int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
  * ---------------------------------------------------------------------- */
 int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
                      float *y, int64_t ldy, float *mean, float *rstd, int64_t rows, int32_t C,
-                     float eps, int32_t act, ac_stream_t stream);
+                     float eps, int32_t act, void *y16, int64_t ldy16, ac_stream_t stream);
+/* y16 (nullable): bf16 copy of the output for the matrix product that follows (y may then be NULL);
+ * available when C = 4*G*J with G in {8,16,32,64}, J in {1,2,3,6} (AC_EALIGN otherwise). */
 int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
                      float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,

@@ -148,7 +148,8 @@ def test_linear_residual_colscale(dev):
 
 # ----------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,C", [(1000, 96), (333, 192), (64, 3072), (512, 5), (100, 130), (5000, 384),
-                                    (700, 768), (300, 1536), (2000, 16), (9, 288)])
+                                    (700, 768), (300, 1536), (2000, 16), (9, 288), (4099, 64), (1237, 128),
+                                    (801, 256), (77, 512), (3, 32), (20001, 64)])
 @pytest.mark.parametrize("act", [None, "gelu"])
 def test_layernorm(dev, rows, C, act):
     from applecider_amd import hipops as H
@@ -167,6 +168,23 @@ def test_layernorm(dev, rows, C, act):
     close(xd.grad, x.grad, name="dx")
     close(wd.grad, w.grad, name="dgamma")
     close(bd.grad, b.grad, name="dbeta")
+
+
+@pytest.mark.parametrize("rows,C", [(1001, 64), (515, 96), (300, 128), (70, 384), (33, 1536)])
+def test_layernorm_bf16_side_output(dev, bf16_mode, rows, C):
+    """bf16 mode: LayerNorm leaves a bf16 copy of its output for the next matrix product; it must
+    equal the rounding of the fp32 output, and Linear must pick it up (same result as a cast)."""
+    from applecider_amd import hipops as H
+    x = g(dev, rows, C, seed=1).to(dev)
+    w, b = (1 + 0.1 * g(dev, C, seed=2)).to(dev), (0.1 * g(dev, C, seed=3)).to(dev)
+    y = H.layer_norm(x, w, b, 1e-5, act="gelu")
+    side = getattr(y, "_ac16", None)
+    assert side is not None and side.dtype == torch.bfloat16
+    assert torch.equal(side, y.bfloat16())
+    wl = (g(dev, 64, C, seed=5) / 8).to(dev)
+    out = H.linear(y, wl, None)
+    y2 = y.clone()                      # no side output attached: the cast path
+    close(out, H.linear(y2, wl, None), tol=0, name="linear from side output")
 
 
 # ----------------------------------------------------------------------------- image branch
@@ -703,7 +721,7 @@ def test_mlp_bf16_relu_dropout_matches_unfused(dev, bf16_mode):
     zeros = float((a[0] - x.to(dev) == 0).float().mean())
     assert 0.3 < zeros < 0.5, zeros                     # dropout2 really dropped ~p of the update
     for name, u, v, tol in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), a, b,
-                               (1e-5, 5e-4, 5e-4, 5e-3, 1e-5, 1e-5)  # db1: summed from the bf16 hidden gradient):
+                               (1e-5, 5e-4, 5e-4, 5e-3, 1e-5, 1e-5)):  # db1: summed from the bf16 hidden gradient
         close(u, v, tol=tol, name=name)
     # eval mode: no dropout, still the fused path
     xd, w1d, b1d, w2d, b2d = (t(a_) for a_ in (x, w1, b1, w2, b2))
