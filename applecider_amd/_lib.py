@@ -73,9 +73,11 @@ SIGNATURES = {
     "ac_cast_bf16": [_P, _P, _I64, _P],
     "ac_transpose_cast_bf16": [_P, _I64, _P, _I64, _I64, _I32, _P],
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _P],
-    "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P],
+    "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
+                         _P, _I64, _I32, _I32, _I32, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_colsum_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ac_cast_bf16_colsum": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "ac_act_fwd": [_P, _P, _I64, _I32, _P],
     "ac_copy2d": [_P, _I64, _P, _I64, _I64, _I32, _P],
@@ -83,7 +85,7 @@ SIGNATURES = {
     "ac_gate_fwd": [_P, _P, _P, _P, _I64, _P],
     "ac_gate_bwd": [_P, _P, _P, _P, _P, _I64, _P],
     "ac_dropout": [_P, _P, _I64, _F, _U64, _U64, _P],
-    "ac_layerscale_bwd": [_P, _P, _P, _P, _P, _I64, _I32, _P],
+    "ac_layerscale_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "ac_add": [_P, _P, _P, _I64, _F, _P],
     "ac_scale_by_dev": [_P, _I64, _P, _P],
     "ac_stem_patchify": [_P, _P, _I32, _I32, _I32, _I32, _P],

@@ -209,6 +209,115 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small planes (S x S, S = 1 or 3: the last two ConvNeXt stages at 63x63 input).  Every output
+// pixel sees every input pixel (|offset| <= 2 < 4), so the convolution is a dense S^2 x S^2 product
+// per channel over the (2S-1)^2 central taps: thread = channel, all pixels of a sample in
+// registers, samples looped per thread, no LDS plane and no barriers in the loop.  The general
+// kernel spent ~100 us per launch here on its per-sample load -> barrier -> compute chain.
+// ---------------------------------------------------------------------------------------------
+constexpr int SM_SLOTS = 4;  // sample slots per workgroup (256 threads = 64 channels x 4 slots)
+
+template <int S>
+__global__ __launch_bounds__(256) void dwconv_small_fwd_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ bias,
+                                                               float *__restrict__ y, int B, int C,
+                                                               int spb) {
+    constexpr int P = S * S, T = 2 * S - 1;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slot = threadIdx.x >> 6;
+    if (c >= C) return;
+    float wt[T * T];
+#pragma unroll
+    for (int ty = 0; ty < T; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) wt[ty * T + tx] = w[((ty + 4 - S) * 7 + (tx + 4 - S)) * C + c];
+    const float bv = bias ? bias[c] : 0.f;
+    const int b1 = min(B, (int)(blockIdx.y + 1) * spb);
+    for (int b = blockIdx.y * spb + slot; b < b1; b += SM_SLOTS) {
+        float xi[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) xi[i] = x[((int64_t)b * P + i) * C + c];
+#pragma unroll
+        for (int o = 0; o < P; ++o) {
+            float a = bv;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int ty = i / S - o / S + S - 1, tx = i % S - o % S + S - 1;
+                a = fmaf(xi[i], wt[ty * T + tx], a);
+            }
+            y[((int64_t)b * P + o) * C + c] = a;
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__restrict__ dy,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ w,
+                                                               float *__restrict__ dx,
+                                                               float *__restrict__ dw,
+                                                               float *__restrict__ dbias, int B,
+                                                               int C, int spb) {
+    constexpr int P = S * S, T = 2 * S - 1;
+    __shared__ float red[SM_SLOTS][T * T + 1][64];
+    const int cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cv = c < C;
+    float wt[T * T], dwa[T * T];
+    float dba = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < T; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) {
+            wt[ty * T + tx] = cv ? w[((ty + 4 - S) * 7 + (tx + 4 - S)) * C + c] : 0.f;
+            dwa[ty * T + tx] = 0.f;
+        }
+    const int b1 = min(B, (int)(blockIdx.y + 1) * spb);
+    if (cv) {
+        for (int b = blockIdx.y * spb + slot; b < b1; b += SM_SLOTS) {
+            float xi[P], d[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                xi[i] = x[((int64_t)b * P + i) * C + c];
+                d[i] = dy[((int64_t)b * P + i) * C + c];
+                dba += d[i];
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int o = 0; o < P; ++o) {
+                    const int ty = i / S - o / S + S - 1, tx = i % S - o % S + S - 1;
+                    a = fmaf(d[o], wt[ty * T + tx], a);
+                    dwa[ty * T + tx] = fmaf(d[o], xi[i], dwa[ty * T + tx]);
+                }
+                dx[((int64_t)b * P + i) * C + c] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < T * T; ++k) red[slot][k][cl] = dwa[k];
+    red[slot][T * T][cl] = dba;
+    __syncthreads();
+    if (cv) {
+        for (int k = slot; k <= T * T; k += SM_SLOTS) {
+            const float sum = (red[0][k][cl] + red[1][k][cl]) + (red[2][k][cl] + red[3][k][cl]);
+            if (k < T * T) {
+                const int ty = k / T, tx = k % T;
+                atomicAdd(&dw[((ty + 4 - S) * 7 + (tx + 4 - S)) * C + c], sum);
+            } else if (dbias) {
+                atomicAdd(&dbias[c], sum);
+            }
+        }
+    }
+}
+
+inline int small_spb(int B) {  // samples per workgroup: ~32 workgroups along the batch
+    int spb = (B + 31) / 32;
+    return spb < SM_SLOTS ? SM_SLOTS : spb;
+}
+
 template <int XS>
 int launch_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W,
                int C, hipStream_t stream) {
@@ -240,6 +349,16 @@ extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bia
                                 int32_t B, int32_t H, int32_t W, int32_t C, ac_stream_t stream_) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    if (H == W && (W == 1 || W == 3)) {
+        const int spb = small_spb(B);
+        dim3 grid((C + 63) / 64, (B + spb - 1) / spb);
+        if (W == 1)
+            hipLaunchKernelGGL(dwconv_small_fwd_kernel<1>, grid, dim3(256), 0, stream, x, w, bias, y, B, C, spb);
+        else
+            hipLaunchKernelGGL(dwconv_small_fwd_kernel<3>, grid, dim3(256), 0, stream, x, w, bias, y, B, C, spb);
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
     if (W == 1) return launch_fwd<1>(x, w, bias, y, B, H, W, C, stream);
     if (W <= 3) return launch_fwd<3>(x, w, bias, y, B, H, W, C, stream);
     if (W == 7) return launch_fwd<7>(x, w, bias, y, B, H, W, C, stream);
@@ -251,6 +370,16 @@ extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w,
                                 int32_t C, ac_stream_t stream_) {
     if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    if (H == W && (W == 1 || W == 3)) {
+        const int spb = small_spb(B);
+        dim3 grid((C + 63) / 64, (B + spb - 1) / spb);
+        if (W == 1)
+            hipLaunchKernelGGL(dwconv_small_bwd_kernel<1>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb);
+        else
+            hipLaunchKernelGGL(dwconv_small_bwd_kernel<3>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb);
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
     if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);

@@ -67,20 +67,25 @@ __global__ void scale_by_dev_kernel(float *x, int64_t n, const float *s) {
 // dyl = dy*gamma; dgamma[c] += sum_rows dy*ylin.  Workgroup = slab of rows, thread = channel.
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float *dy, const float *ylin,
                                                              const float *gamma, float *dyl,
-                                                             float *dgamma, int64_t rows, int C,
+                                                             unsigned short *dyl16, float *dgamma,
+                                                             float *dbias, int64_t rows, int C,
                                                              int rows_per_block) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     for (int c = threadIdx.x; c < C; c += 256) {
         const float g = gamma[c];
-        float s = 0.f;
+        float s = 0.f, sd = 0.f;
         for (int64_t r = r0; r < r1; ++r) {
             const float d = dy[r * C + c];
             s += d * ylin[r * C + c];
-            dyl[r * C + c] = d * g;
+            sd += d;
+            const float o = d * g;
+            if (dyl) dyl[r * C + c] = o;
+            if (dyl16) dyl16[r * C + c] = __builtin_bit_cast(unsigned short, __float2bfloat16(o));
         }
         atomicAdd(&dgamma[c], s);
+        if (dbias) atomicAdd(&dbias[c], sd * g);
     }
 }
 
@@ -388,13 +393,15 @@ extern "C" int ac_scale_by_dev(float *x, int64_t n, const float *s, ac_stream_t 
     EW_LAUNCH(scale_by_dev_kernel, n, x, n, s);
 }
 extern "C" int ac_layerscale_bwd(const float *dy, const float *ylin, const float *gamma,
-                                 float *dyl, float *dgamma, int64_t rows, int32_t C,
-                                 ac_stream_t stream) {
-    if (!dy || !ylin || !gamma || !dyl || !dgamma || rows <= 0 || C <= 0) return AC_EINVAL;
+                                 float *dyl, void *dyl16, float *dgamma, float *dbias,
+                                 int64_t rows, int32_t C, ac_stream_t stream) {
+    if (!dy || !ylin || !gamma || (!dyl && !dyl16) || !dgamma || rows <= 0 || C <= 0)
+        return AC_EINVAL;
     int rpb = 32;
     while ((rows + rpb - 1) / rpb > 4096) rpb *= 2;
     hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0,
-                       (hipStream_t)stream, dy, ylin, gamma, dyl, dgamma, rows, C, rpb);
+                       (hipStream_t)stream, dy, ylin, gamma, dyl, (unsigned short *)dyl16, dgamma,
+                       dbias, rows, C, rpb);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
     const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
     int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float *__restrict__ dxsum, int64_t rows, int act) {
+    float *__restrict__ dxsum, int64_t rows, int act, unsigned short *__restrict__ dx16,
+    int64_t lddx16, int seg_len, int seg_pitch, int seg_off) {
     constexpr int RPW = 64 / G, C = 4 * G * J;
     __shared__ __attribute__((aligned(16))) float sacc[3 * C];
     const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -401,7 +402,15 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
                 o[e] = rs * (d[j][e] * g4[j][e] - c1 - xh[j][e] * c2);
                 adx[j][e] += o[e];
             }
-            *(f32x4 *)(dx + r * lddx + 4 * (sub + G * j)) = o;
+            if (dx) *(f32x4 *)(dx + r * lddx + 4 * (sub + G * j)) = o;
+            if (dx16) {
+                // bf16 copy for the matrix products that consume dx; rows may land in a zero-padded
+                // [batch, seg_pitch, C] buffer (row r = (b, l) -> b*seg_pitch + seg_off + l)
+                const int64_t rr = seg_len ? (r / seg_len) * seg_pitch + seg_off + r % seg_len : r;
+                ushort4 h;
+                h.x = ln_bf16(o[0]); h.y = ln_bf16(o[1]); h.z = ln_bf16(o[2]); h.w = ln_bf16(o[3]);
+                *(ushort4 *)(dx16 + rr * lddx16 + 4 * (sub + G * j)) = h;
+            }
         }
     }
     // the 64/G row slots of a wave hold partial sums of the same channels: fold them with
@@ -565,6 +574,41 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     part[ph][cl] = s0 + s1;
     __syncthreads();
     if (ph == 0 && c < cols) atomicAdd(&out[c], (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+}
+
+// y16 = bf16(x) and out[c] += sum_r x[r, c] in one pass (the output gradient of a Linear layer is
+// needed as a bf16 operand AND as its bias gradient): lane = column pair, 4 row phases.
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restrict__ x, int64_t ldx,
+                                                          unsigned short *__restrict__ y16,
+                                                          int64_t ldy, float *__restrict__ out,
+                                                          int64_t rows, int cols, int rows_per_block) {
+    __shared__ float part[4][128];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 128 + 2 * cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + ph; r < r1; r += 4) {
+            const float2 v = *(const float2 *)(x + r * ldx + c);
+            a0 += v.x;
+            a1 += v.y;
+            unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y);
+            u0 += 0x7fffu + ((u0 >> 16) & 1u);
+            u1 += 0x7fffu + ((u1 >> 16) & 1u);
+            *(unsigned *)(y16 + r * ldy + c) = (u0 >> 16) | (u1 & 0xffff0000u);
+        }
+    }
+    part[ph][2 * cl] = a0;
+    part[ph][2 * cl + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.y * 128 + threadIdx.x;
+        if (cc < cols)
+            atomicAdd(&out[cc], (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                    (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    }
 }
 
 // bf16 input (the bf16 hidden gradient the fused MLP backward keeps): a lane owns a column PAIR
@@ -790,8 +834,12 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
                                 const float *mean, const float *rstd, const float *gamma,
                                 const float *beta, float *dx, int64_t lddx, float *dgamma,
                                 float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
-                                ac_stream_t stream_) {
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || rows < 0 || C <= 0) return AC_EINVAL;
+                                void *dx16, int64_t lddx16, int32_t seg_len, int32_t seg_pitch,
+                                int32_t seg_off, ac_stream_t stream_) {
+    if (!dy || !x || !mean || !rstd || !gamma || (!dx && !dx16) || rows < 0 || C <= 0)
+        return AC_EINVAL;
+    if (seg_len < 0 || (seg_len > 0 && (rows % seg_len || seg_pitch < seg_len + seg_off || seg_off < 0)))
+        return AC_EINVAL;
     if (act == AC_ACT_GELU && !beta) return AC_EINVAL;
     if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
     if (C > 4096) return AC_EINVAL;  // 3*C floats of LDS
@@ -803,18 +851,21 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     const bool vec = vec4 && C <= 1536;
     const size_t lds = 3 * (size_t)C * sizeof(float);
     int G = 0, J = 0;
-    if (vec4 && ln_sub_shape(C, &G, &J)) {
+    const bool dx16_ok = !dx16 || (((uintptr_t)dx16 & 7u) == 0 && lddx16 % 4 == 0);
+    if (vec4 && dx16_ok && ln_sub_shape(C, &G, &J)) {
         const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 2048);
 #define LN_BWD_SUB(GG, JJ)                                                                       \
     if (G == GG && J == JJ)                                                                      \
         hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ>), dim3(grid), dim3(ROWS_BLOCK), 0, \
                            stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma,  \
-                           dbeta, dxsum, rows, act);
+                           dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len,     \
+                           seg_pitch, seg_off);
         LN_SUB_CASES(LN_BWD_SUB)
 #undef LN_BWD_SUB
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
+    if (dx16 || !dx) return AC_EALIGN;  // the bf16 output exists on the sub-wave path only
     if (vec4 && !vec && C <= 3072) {
         int64_t g = rows < 2048 ? rows : 2048;
         hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((int)g), dim3(ROWS_BLOCK), 0, stream, dy,
@@ -855,6 +906,26 @@ extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, 
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows,
                        cols, rpb);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_cast_bf16_colsum(const float *x, int64_t ldx, void *y16, int64_t ldy, float *out,
+                                   int64_t rows, int32_t cols, int32_t accumulate,
+                                   ac_stream_t stream) {
+    if (!x || !y16 || !out || rows < 0 || cols <= 0) return AC_EINVAL;
+    if ((cols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)x & 7u) || ((uintptr_t)y16 & 3u))
+        return AC_EALIGN;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    if (rows == 0) return AC_OK;
+    int rpb = 128;
+    while ((rows + rpb - 1) / rpb > 4096) rpb *= 2;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 127) / 128));
+    hipLaunchKernelGGL(cast_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (unsigned short *)y16, ldy, out, rows, cols, rpb);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

@@ -311,14 +311,26 @@ class _Linear(Function):
             # y = pre*gamma (+res): dpre = dy*gamma ; dgamma = sum_m dy*pre
             g = torch.empty_like(dy2)
             dcs = torch.zeros_like(colscale)
-            _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), _p(dcs), M,
-                                                 N, _stream()), "ac_layerscale_bwd")
+            _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), None, _p(dcs),
+                                                 None, M, N, _stream()), "ac_layerscale_bwd")
         elif ctx.act != ACT_NONE:
             g = torch.empty_like(dy2)
             _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
                        "ac_act_bwd")
         dx = dw = db = None
-        g16 = cast16(g) if ctx.b16 else None
+        g16 = None
+        bias_done = False
+        if ctx.b16:
+            bsink = _sink(ctx.bp) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+            if bsink is not None and N % 2 == 0:
+                # one pass over g: the bf16 operand copy and the bias gradient (into its sink)
+                g16 = torch.empty(M, N, device=dy.device, dtype=torch.bfloat16)
+                _lib.check(_lib_().ac_cast_bf16_colsum(_p(g), N, _p(g16), N, _p(bsink), M, N, 1,
+                                                       _stream()), "ac_cast_bf16_colsum")
+                _grad_written(ctx.bp)
+                bias_done = True
+            else:
+                g16 = cast16(g)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             if ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
@@ -340,7 +352,7 @@ class _Linear(Function):
             if wsink is not None:
                 dw = None
                 _grad_written(ctx.wp)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if ctx.has_b and ctx.needs_input_grad[2] and not bias_done:
             bsink = _sink(ctx.bp)
             if bsink is not None:
                 _lib.check(_lib_().ac_colsum(_p(g), N, _p(bsink), M, N, 1, _stream()), "ac_colsum")
@@ -408,14 +420,26 @@ class _MLP(Function):
         if ctx.p2 > 0:
             g2 = torch.empty_like(dy2)
             _lib.check(lib.ac_dropout(_p(dy2), _p(g2), M * N, ctx.p2, ctx.seed2, 0, st), "ac_dropout")
-        dcs = None
+        dcs = db2 = None
+        b2sink = _sink(b2p) if (b2p is not None and ctx.needs_input_grad[4]) else None
+        g2_16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         if colscale is not None:
-            src, g2 = g2, torch.empty_like(dy2)
+            # layer scale: bf16 gradient of the linear output, dgamma and the bias gradient in one pass
             dcs = torch.zeros_like(colscale)
-            _lib.check(lib.ac_layerscale_bwd(_p(src), _p(pre2), _p(colscale), _p(g2), _p(dcs), M, N, st),
-                       "ac_layerscale_bwd")
-        g2_16 = cast16(g2)
-        db2 = _bias_grad(b2p, g2, M, N, ctx.needs_input_grad[4])
+            if b2p is not None and ctx.needs_input_grad[4] and b2sink is None:
+                db2 = torch.zeros(N, device=dev, dtype=torch.float32)
+            dbp = b2sink if b2sink is not None else db2
+            _lib.check(lib.ac_layerscale_bwd(_p(g2), _p(pre2), _p(colscale), None, _p(g2_16), _p(dcs),
+                                             _p(dbp), M, N, st), "ac_layerscale_bwd")
+            if b2sink is not None:
+                _grad_written(b2p)
+        elif b2sink is not None and N % 2 == 0:
+            _lib.check(lib.ac_cast_bf16_colsum(_p(g2), N, _p(g2_16), N, _p(b2sink), M, N, 1, st),
+                       "ac_cast_bf16_colsum")
+            _grad_written(b2p)
+        else:
+            g2_16 = cast16(g2)
+            db2 = _bias_grad(b2p, g2, M, N, ctx.needs_input_grad[4])
         # ---- dW2 = g2^T @ hidden
         dw2 = _weight_grad(w2p, g2_16, N, g16, Hd, M, ctx.needs_input_grad[3])
         # ---- hidden gradient, bf16 only: (g2 @ W2) * act'(.) [* dropout1 mask]
@@ -535,7 +559,7 @@ class _LayerNorm(Function):
         db = bs if both else torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
                                             _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
-                                            ctx.act, _stream()), "ac_layernorm_bwd")
+                                            ctx.act, None, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
         if both:
             _grad_written(ctx.gp)
             _grad_written(ctx.bp)
@@ -1092,21 +1116,43 @@ class _ConvGroup1d(Function):
         dev = dycat.device
         dycat = _chk(dycat, "dycat")
         dgam = dbet = bias_sums = None
+        Lp = ctx.Lp
+        b16 = ctx.b16
+        mth = _lib.MATH_BF16_IN if b16 else None
+        need_dx = Cin != 1 and ctx.needs_input_grad[0]
+        Lpd = L + 2 * Pmax
+        dypad = dyop = None
         if ctx.fused_ln:
             saved = ctx.saved_tensors
             xpad, ws = saved[0], list(saved[1:1 + nconv])
             ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:]
-            dpre = torch.empty_like(ycat)
             gsink, bsink = _sink(ctx.params[1]), _sink(ctx.params[2])
             ln_direct = gsink is not None and bsink is not None
             dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
             dbet = bsink if ln_direct else torch.zeros_like(ln_beta)
             fuse_bias = Ncat % 4 == 0 and Ncat <= 3072
             bias_sums = torch.zeros(Ncat, device=dev, dtype=torch.float32) if fuse_bias else None
+            # bf16 mode: the LayerNorm backward writes the bf16 operand of the gradient products
+            # directly (into the zero-padded buffer when the input gradient is needed); the fp32
+            # gradient of the conv outputs is never materialised
+            direct16 = b16 and fuse_bias and _ln_sub_shape(Ncat)
+            dpre, seg = None, (0, 0, 0)
+            if direct16 and need_dx:
+                dypad = torch.empty(B, Lpd, Ncat, device=dev, dtype=torch.bfloat16)
+                if Pmax > 0:
+                    dypad[:, :Pmax].zero_()
+                    dypad[:, Pmax + L:].zero_()
+                out16, seg = dypad, (L, Lpd, Pmax)
+            elif direct16:
+                dyop = torch.empty(B * L, Ncat, device=dev, dtype=torch.bfloat16)
+                out16 = dyop
+            else:
+                dpre, out16 = torch.empty_like(ycat), None
             _lib.check(_lib_().ac_layernorm_bwd(_p(dycat), Ncat, _p(ycat), Ncat, _p(mean), _p(rstd),
                                                 _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
                                                 _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
-                                                _stream()), "ac_layernorm_bwd")
+                                                _p(out16), Ncat, seg[0], seg[1], seg[2], _stream()),
+                       "ac_layernorm_bwd")
             dycat = dpre
             if ln_direct:
                 dgam = dbet = None
@@ -1122,21 +1168,17 @@ class _ConvGroup1d(Function):
                 return bias_sums[j * Cout:(j + 1) * Cout]
             return colsum(_p(dycat, j * Cout), Ncat, B * L, Cout, dev)
 
-        Lp = ctx.Lp
         grads = []
         dx = None
-        b16 = ctx.b16
-        mth = _lib.MATH_BF16_IN if b16 else None
-        need_dx = Cin != 1 and ctx.needs_input_grad[0]
-        Lpd = L + 2 * Pmax
-        if need_dx:
+        if need_dx and dypad is None:
             # one zero-padded (bf16 in bf16 mode) copy of d(ycat) serves the input-gradient products
             # (as the window / gathered operand) and the weight-gradient products (rows Pmax..Pmax+L)
             dypad = (_pad_rows16 if b16 else _pad_rows)(dycat, B, L, Ncat, Pmax, Lpd)
         if b16 and need_dx:
             dy_mat = lambda j: mat(_p(dypad, Pmax * Ncat + j * Cout), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat)
         else:
-            dyop = cast16(dycat) if b16 else dycat  # A operand of the dW products
+            if dyop is None:
+                dyop = cast16(dycat) if b16 else dycat  # A operand of the dW products
             dy_mat = lambda j: mat(_p(dyop, j * Cout), Ncat)
         if Cin == 1:
             Lq = L // 8

@@ -178,7 +178,11 @@ int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const floa
 int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
                      float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
-                     int64_t rows, int32_t C, int32_t act, ac_stream_t stream);
+                     int64_t rows, int32_t C, int32_t act, void *dx16, int64_t lddx16,
+                     int32_t seg_len, int32_t seg_pitch, int32_t seg_off, ac_stream_t stream);
+/* dx16 (nullable, same C restriction as y16; dx may then be NULL): bf16 copy of dx.  With
+ * seg_len > 0 row r = (b, l), l < seg_len, is written to row b*seg_pitch + seg_off + l of dx16 —
+ * the zero-padded [B, Lp, C] operand of the Conv1d gradient products (pads are the caller's). */
 
 /* ------------------------------------------------------------------------
  * Elementwise / reduction helpers.
@@ -186,6 +190,9 @@ int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
 /* out[n] (+)= sum_m x[m,n]  — bias gradients. */
 int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
               int32_t accumulate, ac_stream_t stream);
+/* y16 = bf16(x) and out[n] (+)= sum_m x[m,n] in one pass (cols, ldx, ldy even). */
+int ac_cast_bf16_colsum(const float *x, int64_t ldx, void *y16, int64_t ldy, float *out,
+                        int64_t rows, int32_t cols, int32_t accumulate, ac_stream_t stream);
 /* The same for a bf16 matrix (cols and ldx even): bias gradient of a bf16 hidden gradient. */
 int ac_colsum_bf16(const void *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
                    int32_t accumulate, ac_stream_t stream);
@@ -209,9 +216,12 @@ int ac_gate_bwd(const float *dout, const float *a, const float *g, float *da, fl
 /* y = x * keep(seed, offset + i) / (1-p); the same call with dy gives dx (nn.Dropout). */
 int ac_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
                ac_stream_t stream);
-/* ConvNeXt layer-scale backward: dyl = dy*gamma[n]; dgamma[n] += sum_m dy*ylin (atomics). */
+/* ConvNeXt layer-scale backward: dyl = dy*gamma[n] (fp32 and/or bf16 copy, either nullable);
+ * dgamma[n] += sum_m dy*ylin; dbias[n] (nullable) += sum_m dyl = the bias gradient of the linear
+ * layer under the scale (atomics: zero dgamma / dbias first). */
 int ac_layerscale_bwd(const float *dy, const float *ylin, const float *gamma, float *dyl,
-                      float *dgamma, int64_t rows, int32_t C, ac_stream_t stream);
+                      void *dyl16, float *dgamma, float *dbias, int64_t rows, int32_t C,
+                      ac_stream_t stream);
 /* y = (a + b) * alpha. */
 int ac_add(const float *a, const float *b, float *y, int64_t n, float alpha, ac_stream_t stream);
 /* x *= s[0] * scale  (device scalar; gradient clipping). */
