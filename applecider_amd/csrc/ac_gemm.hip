@@ -885,6 +885,45 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float *_
     }
 }
 
+// All 2-D weights of a flat parameter buffer in ONE launch: segment s = {offset, rows, cols,
+// first tile}; dst holds, at the same offset, the [cols, rows] bf16 transpose.  (One launch per
+// weight per optimizer step cost ~100 launches of ~10 us.)
+__global__ __launch_bounds__(256) void transpose_cast_segments_kernel(
+    const float *__restrict__ src, unsigned short *__restrict__ dst, const int64_t *__restrict__ segs,
+    int nseg) {
+    __shared__ float tile[64][65];
+    __shared__ int sseg;
+    const int tileid = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = nseg - 1;  // last segment whose first tile <= tileid
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (segs[4 * mid + 3] <= tileid) lo = mid; else hi = mid - 1;
+        }
+        sseg = lo;
+    }
+    __syncthreads();
+    const int64_t off = segs[4 * sseg], rows = segs[4 * sseg + 1], cols = segs[4 * sseg + 2];
+    const int local = tileid - (int)segs[4 * sseg + 3];
+    const int tcols = (int)((cols + 63) / 64);
+    const int64_t r0 = (int64_t)(local / tcols) * 64;
+    const int c0 = (local % tcols) * 64;
+    const float *x = src + off;
+    unsigned short *y = dst + off;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t rr = r0 + i;
+        const int cc = c0 + tx;
+        tile[i][tx] = (rr < rows && cc < cols) ? x[rr * cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int cc = c0 + i;
+        const int64_t rr = r0 + tx;
+        if (cc < cols && rr < rows) y[(int64_t)cc * rows + rr] = f2bf(tile[tx][i]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Scalar kernel for tiny or unaligned products (metadata towers, router, class
 // heads: K, N of 2..48).  One thread per output element.
@@ -1077,6 +1116,15 @@ extern "C" int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int6
     dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
     hipLaunchKernelGGL(transpose_cast_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx,
                        (unsigned short *)y, ldy, rows, cols);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_transpose_cast_segments(const float *src, void *dst, const int64_t *segs,
+                                          int32_t nseg, int32_t total_tiles, ac_stream_t stream) {
+    if (!src || !dst || !segs || nseg <= 0 || total_tiles <= 0) return AC_EINVAL;
+    hipLaunchKernelGGL(transpose_cast_segments_kernel, dim3(total_tiles), dim3(256), 0,
+                       (hipStream_t)stream, src, (unsigned short *)dst, segs, nseg);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

@@ -122,6 +122,15 @@ def cast16(t: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def cast16_into(src: torch.Tensor, dst: torch.Tensor):
+    _lib.check(_lib_().ac_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "ac_cast_bf16")
+
+
+def transpose_cast_segments(src, dst, segs, nseg, tiles):
+    _lib.check(_lib_().ac_transpose_cast_segments(_p(src), _p(dst), _p(segs), nseg, tiles, _stream()),
+               "ac_transpose_cast_segments")
+
+
 def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
     """[R, C] fp32 -> [C, R] bf16."""
     R, Cc = t2d.shape
@@ -153,13 +162,49 @@ def _cached(t: torch.Tensor, kind: str, fn):
     return v
 
 
+# bf16 mirrors of a flat parameter buffer (applecider_amd.optim.FlatParameters): the whole buffer is
+# cast, and every 2-D weight transposed, by two launches per optimizer step; the bf16 operand of a
+# product is then a view.  Keyed by parameter identity; validated against the flat buffer's version
+# counter (any torch-level write to a parameter bumps it) and the optimizer's dirty flag.
+_mirror_owner: dict = {}
+
+
+def register_mirror(fp):
+    for i, p in enumerate(fp.params):
+        _mirror_owner[id(p)] = (weakref.ref(p), weakref.ref(fp), i)
+
+
+def _mirror(w, transposed: bool):
+    ent = _mirror_owner.get(id(w))
+    if ent is None or ent[0]() is not w:
+        return None
+    fp = ent[1]()
+    if fp is None or fp.flat is None or not fp.flat.is_cuda:
+        return None
+    off, n = fp.offsets[ent[2]], w.numel()
+    if w.data_ptr() != fp.flat.data_ptr() + 4 * off:
+        return None
+    # stale when the optimizer stepped (raw-pointer update: dirty flag), when the flat buffer was
+    # written through torch (broadcast), or when this parameter was (load_state_dict, init)
+    if (fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
+            or fp.mirror_pver[ent[2]] != w._version):
+        fp.refresh_mirrors()
+    if transposed:
+        if w.dim() != 2:
+            return None
+        return fp.flatT16[off:off + n].view(w.shape[1], w.shape[0])
+    return fp.flat16[off:off + n].view(w.shape)
+
+
 def cast16_w(w):
     """bf16 copy of a weight, computed once per optimizer step."""
-    return _cached(w, "c", cast16)
+    m = _mirror(w, False)
+    return m if m is not None else _cached(w, "c", cast16)
 
 
 def cast16_wT(w2d):
-    return _cached(w2d, "t", cast16_T)
+    m = _mirror(w2d, True)
+    return m if m is not None else _cached(w2d, "t", cast16_T)
 
 
 # Gradient sinks: when a parameter already owns a contiguous fp32 .grad (the flat gradient buffer of

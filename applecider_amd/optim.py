@@ -36,6 +36,8 @@ class FlatParameters:
                 self.params.append(p)
         self.flat: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
+        self.flat16 = self.flatT16 = None
+        self.mirror_dirty, self.mirror_version = True, -1
         self.offsets: List[int] = []
         self.group_ranges: List[tuple] = []
 
@@ -70,6 +72,30 @@ class FlatParameters:
                 p.data = flat[off:off + n].view(p.shape)
                 p.grad = grad[off:off + n].view(p.shape)
         self.flat, self.grad, self.offsets, self.group_ranges = flat, grad, offsets, ranges
+        self.flat16 = self.flatT16 = None
+        self.mirror_dirty, self.mirror_version = True, -1
+        if flat.is_cuda:
+            H.register_mirror(self)
+
+    def refresh_mirrors(self):
+        """bf16 copies of all parameters (and the transposes of the 2-D ones) in two launches."""
+        if self.flat16 is None:
+            self.flat16 = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
+            self.flatT16 = torch.empty_like(self.flat16)
+            segs, tiles = [], 0
+            for p, off in zip(self.params, self.offsets):
+                if p.dim() == 2:
+                    r, c = p.shape
+                    segs += [off, r, c, tiles]
+                    tiles += -(-r // 64) * -(-c // 64)
+            self._nseg, self._tiles = len(segs) // 4, tiles
+            self._segs = (torch.tensor(segs, dtype=torch.int64, device=self.flat.device)
+                          if segs else None)
+        H.cast16_into(self.flat, self.flat16)
+        if self._segs is not None:
+            H.transpose_cast_segments(self.flat, self.flatT16, self._segs, self._nseg, self._tiles)
+        self.mirror_dirty, self.mirror_version = False, self.flat._version
+        self.mirror_pver = [p._version for p in self.params]
 
     def ensure(self):
         if not self.is_current():
@@ -135,6 +161,7 @@ class FlatAdam:
         H.adam_flat(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_count,
                     getattr(self, "_clip", None))
         self._clip = None
+        self.fp.mirror_dirty = True
         H.clear_step_cache()  # cached bf16 weight copies are stale now
 
     @property
@@ -172,6 +199,7 @@ class FlatSGD:
         H.sgd_flat(self.fp.flat, self.fp.grad, self.buf, float(g["lr"]), float(g["momentum"]),
                    float(g["weight_decay"]), self.first)
         self.first = False
+        self.fp.mirror_dirty = True
         H.clear_step_cache()
 
     @property

@@ -133,6 +133,11 @@ int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream);
 /* y[c, r] = bf16(x[r, c]) : the k-contiguous bf16 copy of an operand stored row-contiguous. */
 int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int64_t ldy, int64_t rows,
                            int32_t cols, ac_stream_t stream);
+/* Batched form over a flat parameter buffer: segs (device, 4 x int64 per segment) =
+ * {element offset, rows, cols, index of the segment's first 64x64 tile}; for every segment
+ * dst[offset + c*rows + r] = bf16(src[offset + r*cols + c]).  One launch per optimizer step. */
+int ac_transpose_cast_segments(const float *src, void *dst, const int64_t *segs, int32_t nseg,
+                               int32_t total_tiles, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Conv1d with an LDS-resident input window (bf16 operands, fp32 output) — the fast path of the

@@ -737,3 +737,30 @@ def test_colsum_bf16(dev):
     out = torch.zeros(386, device=dev)
     H._lib.check(H._lib_().ac_colsum_bf16(H._p(x), 386, H._p(out), 1000, 386, 0, H._stream()), "colsum")
     close(out, x.float().sum(0), tol=1e-5, name="colsum_bf16")
+
+
+def test_bf16_parameter_mirrors(dev, bf16_mode):
+    """Weights flattened by the optimizer are cast (and transposed) for all layers in two launches per
+    step; the views must track optimizer steps, load_state_dict-style writes and plain tensors."""
+    from applecider_amd import hipops as H
+    from applecider_amd.optim import FlatAdam
+    lin = torch.nn.Linear(72, 40).to(dev)
+    other = torch.nn.Linear(16, 24).to(dev)
+    opt = FlatAdam([{"params": list(lin.parameters()) + list(other.parameters())}], lr=0.1).prepare()
+    w = lin.weight
+    assert torch.equal(H.cast16_w(w), w.detach().bfloat16())
+    assert torch.equal(H.cast16_wT(w), w.detach().t().contiguous().bfloat16())
+    assert H.cast16_w(w).data_ptr() == opt.fp.flat16.data_ptr() + 2 * opt.fp.offsets[0]   # a view
+    assert torch.equal(H.cast16_wT(other.weight), other.weight.detach().t().contiguous().bfloat16())
+    opt.zero_grad()
+    x = torch.randn(64, 72, device=dev)
+    H.linear(x, lin.weight, lin.bias).sum().backward()
+    before = w.detach().clone()
+    opt.step()
+    assert not torch.equal(before, w.detach())
+    assert torch.equal(H.cast16_w(w), w.detach().bfloat16())          # refreshed after the step
+    with torch.no_grad():
+        w.copy_(torch.randn_like(w))                                    # checkpoint-style write
+    assert torch.equal(H.cast16_wT(w), w.detach().t().contiguous().bfloat16())
+    plain = torch.randn(8, 16, device=dev)                             # not a flattened parameter
+    assert torch.equal(H.cast16_w(plain), plain.bfloat16())
