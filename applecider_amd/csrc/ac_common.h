@@ -56,14 +56,20 @@ __device__ __forceinline__ float ac_wave_max(float v) {
     return v;
 }
 
-// Counter-based keep/drop decision shared by forward and backward (dropout):
-// a 64-bit mix (splitmix64 finaliser) of (seed, index) -> uniform in [0,1).
+// Counter-based keep/drop decision shared by forward and backward (dropout): a 32-bit avalanche
+// hash (two multiply-xorshift rounds, the murmur3 finaliser) of (seed, index) -> uniform in [0,1).
+// 32-bit arithmetic on purpose: inside a GEMM epilogue the generator runs at 2 waves per SIMD, and
+// a 64-bit splitmix (three 64x64 multiplies = ~30 VALU ops per element) cost more than the product.
 __device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+    unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x85EBCA77u;
+    h ^= (unsigned)seed;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h += (unsigned)(seed >> 32);
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ int64_t ac_rowaddr(const ac_rowmap &m, int r) {

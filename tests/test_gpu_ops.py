@@ -526,6 +526,12 @@ def test_dropout_stats(dev):
     y1, y2 = H.dropout(x, 0.5, True), H.dropout(x, 0.5, True)
     assert not torch.equal(y1, y2)  # fresh seed per call
     assert H.dropout(x, 0.5, False) is x
+    # the counter hash must not show structure along rows, columns or between consecutive seeds
+    k1, k2 = (y1 != 0).float().reshape(1024, 1024), (y2 != 0).float().reshape(1024, 1024)
+    assert (k1.mean(0) - 0.5).abs().max().item() < 0.08 and (k1.mean(1) - 0.5).abs().max().item() < 0.08
+    for a, b in ((k1[:, 1:], k1[:, :-1]), (k1[1:], k1[:-1]), (k1, k2)):
+        corr = ((a - 0.5) * (b - 0.5)).mean().item() * 4
+        assert abs(corr) < 6e-3, corr
 
 
 def test_optimizers(dev):
