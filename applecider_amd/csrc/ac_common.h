@@ -23,6 +23,35 @@ __device__ __forceinline__ float ac_gelu_grad(float x) {
     float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     return cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
+// Rational erf (odd polynomial / even polynomial on |x| <= 4, the form Eigen and XLA use for
+// float): max abs error 4.5e-7 against the exact function, ~15 FMAs and one division instead of
+// the branchy library routine.  Used by the bf16-mode GEMM epilogues only, where GELU over a
+// 4C-wide hidden layer cost as much as the product itself; the fp32 path keeps erff.
+__device__ __forceinline__ float ac_erf_fast(float x) {
+    x = fminf(fmaxf(x, -4.f), 4.f);
+    const float x2 = x * x;
+    float p = -2.72614225801306e-10f;
+    p = fmaf(p, x2, 2.77068142495902e-08f);
+    p = fmaf(p, x2, -2.10102402082508e-06f);
+    p = fmaf(p, x2, -5.69250639462346e-05f);
+    p = fmaf(p, x2, -7.34990630326855e-04f);
+    p = fmaf(p, x2, -2.95459980854025e-03f);
+    p = fmaf(p, x2, -1.60960333262415e-02f);
+    float q = -1.45660718464996e-05f;
+    q = fmaf(q, x2, -2.13374055278905e-04f);
+    q = fmaf(q, x2, -1.68282697438203e-03f);
+    q = fmaf(q, x2, -7.37332916720468e-03f);
+    q = fmaf(q, x2, -1.42647390514189e-02f);
+    return x * p * __frcp_rn(q);
+}
+__device__ __forceinline__ float ac_gelu_fast(float x) {
+    return 0.5f * x * (1.0f + ac_erf_fast(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float ac_gelu_grad_fast(float x) {
+    const float kInvSqrt2Pi = 0.39894228040143267794f;
+    const float cdf = 0.5f * (1.0f + ac_erf_fast(x * 0.70710678118654752440f));
+    return cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
 __device__ __forceinline__ float ac_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float ac_act(float v, int kind) {

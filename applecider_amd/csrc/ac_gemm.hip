@@ -33,6 +33,7 @@ struct GemmParams {
     ac_gemm_desc d;
     int tiles_m, tiles_n, nkt, kt_per_split;
     int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
+    int epi_var;  // compile-time epilogue variant (AC_EPI_VARIANTS index) or EPI_GENERIC
 };
 
 // round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
@@ -165,12 +166,77 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n
         *c = v;
 }
 
-__device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
-                                               float *wbuf, int row_base, int col_base, int lane) {
+// Compile-time epilogue variants.  The generic epilogue_vec tests a dozen descriptor fields per
+// float4 and (worse) evaluates `ac_act(v, kind)` with a run-time kind inside unrolled loops, which
+// hipcc turns into "compute GELU, sigmoid and tanh, then select": bias + ReLU cost +50 % on a
+// 66048 x 512 x 128 product.  The host picks the variant whose feature mask equals the
+// descriptor's; anything else (and gathered / scattered C) takes the generic path.
+enum : unsigned {
+    E_BIAS = 1u, E_PRE = 2u, E_GELU = 4u, E_RELU = 8u, E_DGELU = 16u, E_MASK16 = 32u, E_CSCALE = 64u,
+    E_DROP = 128u, E_RES = 256u, E_C16 = 512u, E_C32 = 1024u, E_ACC = 2048u,
+    E_FAST = 4096u  // bf16 math modes: rational erf inside GELU / GELU'
+};
+#define AC_EPI_VARIANTS(X)                                                                      \
+    X(0, E_C32) X(1, E_C32 | E_BIAS) X(2, E_C16 | E_BIAS | E_GELU | E_PRE)                       \
+    X(3, E_C16 | E_BIAS | E_RELU | E_DROP) X(4, E_C16 | E_DGELU) X(5, E_C16 | E_MASK16)          \
+    X(6, E_C32 | E_BIAS | E_PRE | E_CSCALE | E_RES) X(7, E_C32 | E_BIAS | E_DROP | E_RES)        \
+    X(8, E_C32 | E_ACC) X(9, E_C32 | E_BIAS | E_RES) X(10, E_C16 | E_BIAS | E_RELU)              \
+    X(11, E_C16 | E_BIAS | E_GELU) X(12, E_C32 | E_BIAS | E_CSCALE | E_RES) X(13, E_C32 | E_BIAS | E_GELU) \
+    X(14, E_C16 | E_BIAS | E_GELU | E_PRE | E_FAST) X(15, E_C16 | E_DGELU | E_FAST)               \
+    X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)
+constexpr int EPI_GENERIC = 255;
+
+template <unsigned F>
+__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int n, f32x4 v) {
+    v *= d.alpha;
+    if constexpr (F & E_BIAS) v += *(const f32x4 *)(d.bias + n);
+    if constexpr (F & E_PRE) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
+    if constexpr (F & E_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (F & E_FAST) ? ac_gelu_fast(v[j]) : ac_gelu(v[j]);
+    }
+    if constexpr (F & E_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    if constexpr (F & E_DGELU) {
+        const f32x4 a = *(const f32x4 *)(d.aux + (int64_t)m * d.ld_aux + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= (F & E_FAST) ? ac_gelu_grad_fast(a[j]) : ac_gelu_grad(a[j]);
+    }
+    if constexpr (F & E_MASK16) {
+        const ushort4 k = *(const ushort4 *)((const unsigned short *)d.mask16 + (int64_t)m * d.ld_mask16 + n);
+        v[0] = epi_bf16_to_f32(k.x) > 0.f ? v[0] : 0.f;
+        v[1] = epi_bf16_to_f32(k.y) > 0.f ? v[1] : 0.f;
+        v[2] = epi_bf16_to_f32(k.z) > 0.f ? v[2] : 0.f;
+        v[3] = epi_bf16_to_f32(k.w) > 0.f ? v[3] : 0.f;
+    }
+    if constexpr (F & E_CSCALE) v *= *(const f32x4 *)(d.colscale + n);
+    if constexpr (F & E_DROP) {
+        const float inv_keep = 1.0f / (1.0f - d.drop_p);
+        const uint64_t i0 = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(d.drop_seed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
+    }
+    if constexpr (F & E_RES) v += *(const f32x4 *)(d.residual + (int64_t)m * d.ld_res + n);
+    if constexpr (F & E_C16) {
+        ushort4 h;
+        h.x = epi_bf16(v[0]); h.y = epi_bf16(v[1]); h.z = epi_bf16(v[2]); h.w = epi_bf16(v[3]);
+        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + n) = h;
+    }
+    if constexpr (F & E_C32) {
+        f32x4 *c = (f32x4 *)((float *)d.c.ptr + (int64_t)m * d.c.rows.s3 + n);  // plain row-major C
+        if constexpr (F & E_ACC) *c += v; else *c = v;
+    }
+}
+
+template <int VAR>
+__device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+                                                 float *wbuf, int row_base, int col_base, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = col_base + c4;
-    const int64_t coff = n < d.N ? inner_off(d.c.goff, n) : 0;
+    const int64_t coff = (VAR == EPI_GENERIC && n < d.N) ? inner_off(d.c.goff, n) : 0;
     // compile-time indices into acc throughout: a loop the compiler declines to unroll would index
     // the accumulators dynamically and push all 64 of them to scratch
     static_for<0, 2>([&](auto sidx) {
@@ -185,9 +251,28 @@ __device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, const f32x
             const int r = it * 4 + rsub;
             const f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4);
             const int m = row_base + sa * 32 + r;
-            if (m < d.M && n < d.N) epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
+            if (m < d.M && n < d.N) {
+                if constexpr (VAR == EPI_GENERIC) {
+                    epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
+                } else {
+#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v);
+                    AC_EPI_VARIANTS(AC_EPI_CALL)
+#undef AC_EPI_CALL
+                }
+            }
         }
     });
+}
+
+__device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, int variant,
+                                               const f32x16 (&acc)[2][2], float *wbuf, int row_base,
+                                               int col_base, int lane) {
+    switch (variant) {
+#define AC_EPI_CASE(I, F) case I: store_tile_vec_t<I>(d, acc, wbuf, row_base, col_base, lane); break;
+        AC_EPI_VARIANTS(AC_EPI_CASE)
+#undef AC_EPI_CASE
+        default: store_tile_vec_t<EPI_GENERIC>(d, acc, wbuf, row_base, col_base, lane); break;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -377,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
         store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
@@ -513,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
         store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
@@ -821,7 +906,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
+        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
     else
         store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
 }
@@ -972,6 +1057,30 @@ bool rowmap_aligned(const ac_rowmap &r) {
     return (r.s1 % 4 == 0) && (r.s2 % 4 == 0) && (r.s3 % 4 == 0);
 }
 
+int epilogue_variant(const ac_gemm_desc &d, int accumulate) {
+    if (d.c.rows.r1 != 0 || d.c.goff || accumulate == 2) return EPI_GENERIC;
+    unsigned f = 0;
+    if (d.bias) f |= E_BIAS;
+    if (d.pre_out) f |= E_PRE;
+    if (d.act == AC_ACT_GELU) f |= E_GELU;
+    else if (d.act == AC_ACT_RELU) f |= E_RELU;
+    else if (d.act != AC_ACT_NONE) return EPI_GENERIC;
+    if (d.dact == AC_ACT_GELU) f |= E_DGELU;
+    else if (d.dact != AC_ACT_NONE) return EPI_GENERIC;
+    if (d.mask16) f |= E_MASK16;
+    if (d.colscale) f |= E_CSCALE;
+    if (d.drop_p > 0.f) f |= E_DROP;
+    if (d.residual) f |= E_RES;
+    if (d.c16) f |= E_C16;
+    if (d.c.ptr) f |= E_C32;
+    if (accumulate == 1) f |= E_ACC;
+    if (d.math != AC_MATH_F32 && (f & (E_GELU | E_DGELU))) f |= E_FAST;
+#define AC_EPI_FIND(I, F) if (f == (F)) return I;
+    AC_EPI_VARIANTS(AC_EPI_FIND)
+#undef AC_EPI_FIND
+    return EPI_GENERIC;
+}
+
 int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
     if (accumulate == 2) {  // atomics keep the 128-byte-per-row lane layout
         const bool lean = !d.bias && !d.pre_out && !d.act && !d.dact && !d.colscale && !d.residual &&
@@ -1023,6 +1132,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
         p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
+        p.epi_var = epilogue_variant(p.d, p.d.accumulate);
         // tile shape: force_tile (tests/tuning) or by output shape
         const int tile = d.tile;  // 0 auto, 1 = 128x128, 2 = 256x64, 3 = 256x128 (8 waves)
         if (d.mode == AC_GEMM_TN) {
@@ -1049,6 +1159,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.
         p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = p.vec_epi = 0;
+        p.epi_var = EPI_GENERIC;
         int64_t total = (int64_t)d.M * d.N;
         if (d.mode == AC_GEMM_TN && d.K >= 128 && total <= 65536) {
             hipLaunchKernelGGL(gemm_simple_tn_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0,
@@ -1065,6 +1176,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
     if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
     p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
+    p.epi_var = epilogue_variant(p.d, p.d.accumulate);
     p.tiles_m = (d.M + BM - 1) / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.nkt = (d.K + BK - 1) / BK;
