@@ -187,9 +187,10 @@ enum : unsigned {
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
-__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int n, f32x4 v) {
+__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int n, f32x4 v,
+                                               const f32x4 &bias4, const f32x4 &cs4) {
     v *= d.alpha;
-    if constexpr (F & E_BIAS) v += *(const f32x4 *)(d.bias + n);
+    if constexpr (F & E_BIAS) v += bias4;  // per-column vectors are loaded once per tile
     if constexpr (F & E_PRE) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
     if constexpr (F & E_GELU) {
 #pragma unroll
@@ -211,7 +212,7 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int
         v[2] = epi_bf16_to_f32(k.z) > 0.f ? v[2] : 0.f;
         v[3] = epi_bf16_to_f32(k.w) > 0.f ? v[3] : 0.f;
     }
-    if constexpr (F & E_CSCALE) v *= *(const f32x4 *)(d.colscale + n);
+    if constexpr (F & E_CSCALE) v *= cs4;
     if constexpr (F & E_DROP) {
         const float inv_keep = 1.0f / (1.0f - d.drop_p);
         const uint64_t i0 = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
@@ -237,6 +238,11 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = col_base + c4;
     const int64_t coff = (VAR == EPI_GENERIC && n < d.N) ? inner_off(d.c.goff, n) : 0;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cs4 = {1.f, 1.f, 1.f, 1.f};
+    if (VAR != EPI_GENERIC && n < d.N) {
+        if (d.bias) bias4 = *(const f32x4 *)(d.bias + n);
+        if (d.colscale) cs4 = *(const f32x4 *)(d.colscale + n);
+    }
     // compile-time indices into acc throughout: a loop the compiler declines to unroll would index
     // the accumulators dynamically and push all 64 of them to scratch
     static_for<0, 2>([&](auto sidx) {
@@ -255,7 +261,7 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
                 if constexpr (VAR == EPI_GENERIC) {
                     epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
                 } else {
-#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v);
+#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v, bias4, cs4);
                     AC_EPI_VARIANTS(AC_EPI_CALL)
 #undef AC_EPI_CALL
                 }
