@@ -11,9 +11,10 @@ on a synthetic batch of 512 samples per GPU already resident in HBM.  N > 1: one
 gradient buffer overlapped with backward.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
-  roofline     dominant kernel (the gather-GEMM family that carries the Conv1d implicit GEMMs):
-               algorithmic FLOP / launch duration from HIP events recorded around every launch inside
-               the timed region, against the dense MFMA peak of the math dtype.
+  roofline     dominant kernel family (largest summed launch time; HIP events around every launch in
+               the timed region).  Each launch is rated against the roof that bounds its shape
+               (algorithmic FLOP / dense MFMA peak vs algorithmic bytes / HBM peak); the class holding
+               more of the family's time is `roofline`, the other `roofline_other_class`.
   cpu_baseline the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
                bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -46,6 +47,15 @@ class KernelTimer:
         self.records = {}  # name -> list of (start_event, end_event, work)
         self.enabled = False
 
+    # records hold (start, end, flops, algorithmic bytes).  Algorithmic bytes = every operand and
+    # every output read / written ONCE (unique elements of a Toeplitz / padded view, not the k-fold
+    # re-reads of the implicit GEMM), as SURVEY.md section 8(d) defines the path's byte count.
+    @staticmethod
+    def _operand_elems(m, outer, inner):
+        if m.rows.r1:                        # batched view [outer / r1][r1 rows] with batch stride s1
+            return min(outer * inner, (outer // m.rows.r1) * m.rows.s1 + inner)
+        return outer * inner
+
     def wrap_gemm(self, H):
         orig = H.gemm
         names = {0: "gemm<NT>", 1: "gemm<NN>", 2: "gemm<TN>"}
@@ -59,7 +69,16 @@ class KernelTimer:
             e.record()
             big = float(M) * N * K >= 262144.0  # the MFMA path (scalar kernel below that)
             if big:
-                self.records.setdefault(names[mode], []).append((s, e, 2.0 * M * N * K))
+                es = 2 if kw.get("math") == 2 else 4
+                if mode == 2:
+                    ab = self._operand_elems(a, K, M) + self._operand_elems(b, K, N)
+                else:
+                    ab = self._operand_elems(a, M, K) + self._operand_elems(b, N, K)
+                mn = float(M) * N
+                cb = (4 * mn if c.ptr else 0) + (4 * mn if kw.get("accumulate") == 1 else 0)
+                cb += 2 * mn * (kw.get("c16") is not None) + 2 * mn * (kw.get("mask16") is not None)
+                cb += 4 * mn * sum(kw.get(k) is not None for k in ("pre_out", "aux", "residual"))
+                self.records.setdefault(names[mode], []).append((s, e, 2.0 * M * N * K, es * ab + cb))
         H.gemm = timed
 
     def wrap_conv_window(self, H):
@@ -73,7 +92,8 @@ class KernelTimer:
             ok = orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
             e.record()
             if ok:
-                self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw))
+                byts = 2.0 * B * (L + k - 1) * Cw + 2.0 * N * k * Cw + 4.0 * B * L * N * (2 if acc else 1)
+                self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw, byts))
             return ok
         H.conv_window = timed
 
@@ -92,16 +112,27 @@ class KernelTimer:
             # planes are rated against HBM: the 7x7 / 3x3 / 1x1 stages move < 1/4 of the bytes and are
             # launch-latency bound (a few microseconds each).
             if Hh * Ww >= 100:
-                self.records.setdefault("dwconv7x7_fwd", []).append((s, e, 2.0 * B * Hh * Ww * C * 4))
+                self.records.setdefault("dwconv7x7_fwd", []).append((s, e, 0.0, 2.0 * B * Hh * Ww * C * 4))
             return rc
         lib.ac_dwconv7x7_fwd = timed
 
-    def summary(self):
+    def summary(self, peak_flops, peak_bytes):
+        """Per kernel family: totals, and the same split by which roof bounds each LAUNCH
+        (flops / peak_flops against bytes / peak_bytes — the roofline model applied per shape)."""
         out = {}
         for name, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            work = sum(w for _, _, w in recs)
-            out[name] = {"launches": len(recs), "ms": ms, "work": work}
+            fam = {"launches": len(recs), "ms": 0.0, "flops": 0.0, "bytes": 0.0,
+                   "mfma": {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0},
+                   "hbm": {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}}
+            for s, e, fl, by in recs:
+                ms = s.elapsed_time(e)
+                cls = fam["mfma" if fl / peak_flops >= by / peak_bytes else "hbm"]
+                for d in (fam, cls):
+                    d["ms"] += ms
+                    d["flops"] += fl
+                    d["bytes"] += by
+                cls["launches"] += 1
+            out[name] = fam
         return out
 
 
@@ -185,20 +216,43 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    ks = timer.summary()
+    peak = PEAK_TFLOPS[args.math]
+    ks = timer.summary(peak * 1e12, HBM_PEAK_GBS * 1e9)
     gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d")}
+    # dominant kernel = the family with the largest summed launch time; inside it every launch is
+    # rated against the roof that bounds ITS shape, and the class that holds more of the family's
+    # time is reported as `roofline` (the other class is listed beside it)
     dom_name = max(gemms, key=lambda k: gemms[k]["ms"])
     dom = gemms[dom_name]
-    achieved = dom["work"] / (dom["ms"] * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.math]
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": ("conv1d_window_kernel" if dom_name.startswith("conv1d") else
-                           f"{dom_name} ({'gemm_bf16in_kernel' if args.math == 'bf16' else 'gemm_f32_kernel'})"),
-                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                "all_gemm": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
-                                 "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                             for k, v in gemms.items()}}
+    kname = ("conv1d_window_kernel" if dom_name.startswith("conv1d") else
+             f"{dom_name} ({'gemm_bf16in_kernel' if args.math == 'bf16' else 'gemm_f32_kernel'})")
+
+    def rate(cls, bound):
+        if cls["launches"] == 0:
+            return None
+        sec = cls["ms"] * 1e-3
+        if bound == "mfma":
+            a, pk, unit = cls["flops"] / sec / 1e12, peak, "TFLOP/s"
+        else:
+            a, pk, unit = cls["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        return {"bound": bound, "achieved": round(a, 2), "peak": pk, "unit": unit, "frac": round(a / pk, 4),
+                "traffic": None, "kernel": kname, "launches": cls["launches"],
+                "avg_launch_ms": round(cls["ms"] / cls["launches"], 4),
+                "ms_per_step": round(cls["ms"] / args.steps, 3),
+                "algorithmic_bytes_per_launch": round(cls["bytes"] / cls["launches"]),
+                "algorithmic_flops_per_launch": round(cls["flops"] / cls["launches"])}
+
+    first = "mfma" if dom["mfma"]["ms"] >= dom["hbm"]["ms"] else "hbm"
+    roofline = rate(dom[first], first)
+    other = rate(dom["hbm" if first == "mfma" else "mfma"], "hbm" if first == "mfma" else "mfma")
+    roofline["all_gemm"] = {
+        k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+            "mfma_bound": {"launches": v["mfma"]["launches"], "ms_per_step": round(v["mfma"]["ms"] / args.steps, 3),
+                           "tflops": round(v["mfma"]["flops"] / max(v["mfma"]["ms"], 1e-9) / 1e9, 1)},
+            "hbm_bound": {"launches": v["hbm"]["launches"], "ms_per_step": round(v["hbm"]["ms"] / args.steps, 3),
+                          "GBps": round(v["hbm"]["bytes"] / max(v["hbm"]["ms"], 1e-9) / 1e6, 1)}}
+        for k, v in gemms.items()}
     # HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
     # (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # this same command, FETCH_SIZE doubled for gfx950); None when the kernel is not in that file.
@@ -210,7 +264,8 @@ def main():
             for k, v in pmc.items():
                 if want in k:
                     roofline["traffic"] = round(v["per_launch_MB"] * 1e6)
-                    roofline["traffic_unit"] = "bytes per launch (fabric-side FETCH+WRITE, PMC)"
+                    roofline["traffic_unit"] = ("bytes per launch, average over ALL launches of this kernel "
+                                                "(fabric-side FETCH+WRITE, PMC)")
                     break
     except Exception:
         pass
@@ -226,9 +281,11 @@ def main():
                    "storage_dtype": "f32", "mfma_input_dtype": args.math, "final_loss": round(final_loss, 5)},
         "roofline": roofline,
     }
+    if other is not None:
+        out["roofline_other_class"] = other
     if "dwconv7x7_fwd" in ks:
         d = ks["dwconv7x7_fwd"]
-        gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         out["roofline_hbm"] = {"bound": "hbm", "kernel": "dwconv7x7_fwd_kernel (15x15x96 stage)", "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "traffic": None, "launches": d["launches"]}
