@@ -258,8 +258,8 @@ def main():
     # this same command, FETCH_SIZE doubled for gfx950); None when the kernel is not in that file.
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        want = {"gemm<TN>": "gemm_bf16in_kernel<true, 2, 2>", "gemm<NT>": "gemm_bf16in_kernel<false, 2, 2>",
-                "conv1d_window": "conv1d_window_kernel"}.get(dom_name)
+        want = {"gemm<TN>": "gemm_bf16in_kernelILb1ELi2ELi2EE", "gemm<NT>": "gemm_bf16in_kernelILb0ELi2ELi2EE",
+                "conv1d_window": "conv1d_window_kernel"}.get(dom_name)  # mangled names as rocprofv3 stores them
         if args.math == "bf16" and want:
             for k, v in pmc.items():
                 if want in k:
