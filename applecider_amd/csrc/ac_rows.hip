@@ -352,7 +352,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
     int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ dxsum, int64_t rows, int act, unsigned short *__restrict__ dx16,
-    int64_t lddx16, int seg_len, int seg_pitch, int seg_off) {
+    int64_t lddx16, int seg_len, int seg_pitch, int seg_off, int dy_bf16) {
     constexpr int RPW = 64 / G, C = 4 * G * J;
     __shared__ __attribute__((aligned(16))) float sacc[3 * C];
     const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -374,7 +374,15 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             xh[j] = *(const f32x4 *)(x + r * ldx + 4 * (sub + G * j));
-            d[j] = *(const f32x4 *)(dy + r * lddy + 4 * (sub + G * j));
+            if (dy_bf16) {  // the upstream product handed its input gradient over in bf16
+                const ushort4 h = *(const ushort4 *)((const unsigned short *)dy + r * lddy + 4 * (sub + G * j));
+                d[j][0] = __builtin_bit_cast(float, (unsigned)h.x << 16);
+                d[j][1] = __builtin_bit_cast(float, (unsigned)h.y << 16);
+                d[j][2] = __builtin_bit_cast(float, (unsigned)h.z << 16);
+                d[j][3] = __builtin_bit_cast(float, (unsigned)h.w << 16);
+            } else {
+                d[j] = *(const f32x4 *)(dy + r * lddy + 4 * (sub + G * j));
+            }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -835,7 +843,7 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
                                 const float *beta, float *dx, int64_t lddx, float *dgamma,
                                 float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
                                 void *dx16, int64_t lddx16, int32_t seg_len, int32_t seg_pitch,
-                                int32_t seg_off, ac_stream_t stream_) {
+                                int32_t seg_off, int32_t dy_bf16, ac_stream_t stream_) {
     if (!dy || !x || !mean || !rstd || !gamma || (!dx && !dx16) || rows < 0 || C <= 0)
         return AC_EINVAL;
     if (seg_len < 0 || (seg_len > 0 && (rows % seg_len || seg_pitch < seg_len + seg_off || seg_off < 0)))
@@ -846,7 +854,8 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     if (rows == 0) return AC_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = (C % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) &&
-                      ac_aligned16(dy) && ac_aligned16(x) && ac_aligned16(dx) &&
+                      (dy_bf16 ? (((uintptr_t)dy & 7u) == 0) : ac_aligned16(dy)) && ac_aligned16(x) &&
+                      ac_aligned16(dx) &&
                       ac_aligned16(gamma) && (!beta || ac_aligned16(beta));
     const bool vec = vec4 && C <= 1536;
     const size_t lds = 3 * (size_t)C * sizeof(float);
@@ -859,13 +868,13 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
         hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ>), dim3(grid), dim3(ROWS_BLOCK), 0, \
                            stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma,  \
                            dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len,     \
-                           seg_pitch, seg_off);
+                           seg_pitch, seg_off, dy_bf16);
         LN_SUB_CASES(LN_BWD_SUB)
 #undef LN_BWD_SUB
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
-    if (dx16 || !dx) return AC_EALIGN;  // the bf16 output exists on the sub-wave path only
+    if (dx16 || !dx || dy_bf16) return AC_EALIGN;  // bf16 in/out exist on the sub-wave path only
     if (vec4 && !vec && C <= 3072) {
         int64_t g = rows < 2048 ? rows : 2048;
         hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((int)g), dim3(ROWS_BLOCK), 0, stream, dy,

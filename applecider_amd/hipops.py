@@ -42,7 +42,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(t: torch.Tensor, name="tensor"):
+def _is16only(t) -> bool:
+    return getattr(t, "_ac16_only", False)
+
+
+def _mark16only(t: torch.Tensor, t16: torch.Tensor) -> torch.Tensor:
+    """`t` is an fp32 placeholder that was never written: its value exists as the bf16 tensor t16
+    only (bf16 math mode, producer and consumer are kernels of this package that agreed on it).
+    Any other use of the placeholder is caught by _chk."""
+    t._ac16, t._ac16_only = t16, True
+    return t
+
+
+def _chk(t: torch.Tensor, name="tensor", allow16: bool = False):
+    if not allow16 and _is16only(t):
+        raise RuntimeError(f"{name}: this tensor's fp32 payload was not materialised (bf16-only hand-over "
+                           "between two kernels); its consumer must read the bf16 side tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: applecider_amd kernels need a GPU tensor (no CPU fallback)")
     if t.dtype != torch.float32:
@@ -312,7 +327,8 @@ class _Linear(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, residual, colscale):
-        x = _chk(x, "x")
+        ctx.x16only = _is16only(x)   # producer handed the activation over in bf16 only
+        x = _chk(x, "x", allow16=True)
         w = _chk(w, "w")
         N, K = w.shape
         x2 = x.reshape(-1, K)
@@ -327,6 +343,8 @@ class _Linear(Function):
                                   or colscale is not None)
         pre = torch.empty_like(y) if save_pre else None
         ctx.b16 = bf16_operands() and K % 8 == 0 and N % 8 == 0 and _big(M, N, K)
+        if ctx.x16only and not ctx.b16:
+            raise RuntimeError("bf16-only activation reached a product that is not on the bf16 path")
         x16 = None
         if ctx.b16:
             x16, w16 = cast16_act(x, K), cast16_w(w)
@@ -378,13 +396,24 @@ class _Linear(Function):
                 g16 = cast16(g)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            if ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
+            if ctx.b16 and ctx.x16only:
+                # the producer of x reads its output gradient in bf16 (LayerNorm backward of the conv
+                # bank): write only that; the fp32 tensor autograd carries is a placeholder
+                wT16 = cast16_wT(ctx.wp if ctx.wp.shape == w.shape else w)
+                dx16 = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
+                gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(None, K), c16=dx16,
+                     ld_c16=K, math=_lib.MATH_BF16_IN)
+                dx = _mark16only(dx, dx16.reshape(ctx.shape_x))
+            elif ctx.b16:  # dX = g @ W as NT against the k-contiguous copy W^T [K, N]
                 wT16 = cast16_wT(ctx.wp if ctx.wp.shape == w.shape else w)
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
                      math=_lib.MATH_BF16_IN)
             else:
                 gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
-            dx = dx.reshape(ctx.shape_x)
+            if not _is16only(dx):
+                dx = dx.reshape(ctx.shape_x)
+            elif dx.shape != ctx.shape_x:
+                dx = _mark16only(dx.reshape(ctx.shape_x), dx._ac16)
         if ctx.needs_input_grad[1]:
             wsink = _sink(ctx.wp)
             dw = wsink if wsink is not None else torch.zeros(N, K, device=dy.device, dtype=torch.float32)
@@ -604,7 +633,7 @@ class _LayerNorm(Function):
         db = bs if both else torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
                                             _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
-                                            ctx.act, None, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
+                                            ctx.act, None, 0, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
         if both:
             _grad_written(ctx.gp)
             _grad_written(ctx.bp)
@@ -1065,11 +1094,11 @@ class _ConvGroup1d(Function):
     With ln_gamma/ln_beta the LayerNorm over the 3*Cout channels + GELU of spectranet.py:31-35 is
     applied in the same autograd node, and its backward kernel also emits the column sums of
     d(ycat) — the three bias gradients — so no separate pass over the [B*L, 3*Cout] gradient.
-    args: x, ksizes(tuple), ln_gamma, ln_beta, ln_eps, w0, b0, w1, b1, ...
+    args: x, ksizes(tuple), ln_gamma, ln_beta, ln_eps, out16_only, w0, b0, w1, b1, ...
     """
 
     @staticmethod
-    def forward(ctx, x, ksizes, ln_gamma, ln_beta, ln_eps, *wb):
+    def forward(ctx, x, ksizes, ln_gamma, ln_beta, ln_eps, out16_only, *wb):
         x = _chk(x, "x")
         B, L, Cin = x.shape
         ws = [_chk(w, "w") for w in wb[0::2]]
@@ -1142,10 +1171,14 @@ class _ConvGroup1d(Function):
             mean = torch.empty(rows, device=dev, dtype=torch.float32)
             rstd = torch.empty(rows, device=dev, dtype=torch.float32)
             y16 = _side16_alloc(ycat.shape, Ncat, dev)
-            _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), _p(y), Ncat,
+            only16 = out16_only and y16 is not None   # the consumer reads the bf16 copy: skip fp32
+            _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta),
+                                                None if only16 else _p(y), Ncat,
                                                 _p(mean), _p(rstd), rows, Ncat, ln_eps, ACT_GELU,
                                                 _p(y16), Ncat, _stream()), "ac_layernorm_fwd")
-            if y16 is not None:
+            if only16:
+                _mark16only(y, y16)
+            elif y16 is not None:
                 y._ac16 = y16
             ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta)
             return y
@@ -1159,7 +1192,10 @@ class _ConvGroup1d(Function):
         nconv = len(ksizes)
         Ncat = nconv * Cout
         dev = dycat.device
-        dycat = _chk(dycat, "dycat")
+        dy16in = dycat._ac16 if _is16only(dycat) else None   # gradient handed over in bf16 only
+        dycat = _chk(dycat, "dycat", allow16=True)
+        if dy16in is not None and not ctx.fused_ln:
+            raise RuntimeError("bf16-only gradient reached a conv bank without the fused LayerNorm")
         dgam = dbet = bias_sums = None
         Lp = ctx.Lp
         b16 = ctx.b16
@@ -1193,10 +1229,12 @@ class _ConvGroup1d(Function):
                 out16 = dyop
             else:
                 dpre, out16 = torch.empty_like(ycat), None
-            _lib.check(_lib_().ac_layernorm_bwd(_p(dycat), Ncat, _p(ycat), Ncat, _p(mean), _p(rstd),
+            _lib.check(_lib_().ac_layernorm_bwd(_p(dy16in if dy16in is not None else dycat), Ncat,
+                                                _p(ycat), Ncat, _p(mean), _p(rstd),
                                                 _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
                                                 _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
-                                                _p(out16), Ncat, seg[0], seg[1], seg[2], _stream()),
+                                                _p(out16), Ncat, seg[0], seg[1], seg[2],
+                                                1 if dy16in is not None else 0, _stream()),
                        "ac_layernorm_bwd")
             dycat = dpre
             if ln_direct:
@@ -1282,16 +1320,19 @@ class _ConvGroup1d(Function):
                     dw = None
                     _grad_written(ctx.params[0][j])
                 grads += [dw, bias_grad(j)]
-        return (dx, None, dgam, dbet, None, *grads)
+        return (dx, None, dgam, dbet, None, None, *grads)
 
 
-def conv_group1d(x, ksizes, weights, biases, ln=None):
-    """ln = (gamma, beta, eps) fuses LayerNorm + GELU over the concatenated channels."""
+def conv_group1d(x, ksizes, weights, biases, ln=None, out16_only=False):
+    """ln = (gamma, beta, eps) fuses LayerNorm + GELU over the concatenated channels.
+    out16_only (bf16 math mode, with ln): the caller feeds the result straight into `linear` — the
+    fp32 output is then not written at all (its bf16 copy is), and the gradient comes back in bf16."""
     args = []
     for w, b in zip(weights, biases):
         args += [w, b]
     g, bt, eps = ln if ln is not None else (None, None, 0.0)
-    return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), g, bt, float(eps), *args)
+    return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), g, bt, float(eps),
+                              bool(out16_only and ln is not None), *args)
 
 
 # --------------------------------------------------------------------------- photometry branch

@@ -40,10 +40,19 @@ class SpectraNetBlock(nn.Module):
             self.total_pooled_channels = norm_channels
             self.downsample = PointConv1d(norm_channels, out_channels)
 
+    def _handover16(self, x) -> bool:
+        if not (self.do_pool and H.bf16_operands()):
+            return False
+        n, k = self.downsample.cout, self.downsample.cin   # the 1x1 conv must take the bf16 path
+        return n % 8 == 0 and k % 8 == 0 and H._big(x.shape[0] * x.shape[1], n, k)
+
     def forward(self, x):  # x: [B, L, Cin] channels-last
+        # a pooled block feeds LN+GELU straight into the 1x1 conv: in bf16 mode that hand-over (and
+        # the gradient coming back) is bf16 only — the [B, L, 3*Cout] fp32 tensors are never written
         y = H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs],
                            [c.bias for c in self.convs],
-                           ln=(self.norm.weight, self.norm.bias, self.norm.eps))
+                           ln=(self.norm.weight, self.norm.bias, self.norm.eps),
+                           out16_only=self._handover16(x))
         if self.do_pool:
             y = H.maxpool4(self.downsample(y))
         return y

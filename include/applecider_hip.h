@@ -184,10 +184,13 @@ int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
                      float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
                      int64_t rows, int32_t C, int32_t act, void *dx16, int64_t lddx16,
-                     int32_t seg_len, int32_t seg_pitch, int32_t seg_off, ac_stream_t stream);
+                     int32_t seg_len, int32_t seg_pitch, int32_t seg_off, int32_t dy_bf16,
+                     ac_stream_t stream);
 /* dx16 (nullable, same C restriction as y16; dx may then be NULL): bf16 copy of dx.  With
  * seg_len > 0 row r = (b, l), l < seg_len, is written to row b*seg_pitch + seg_off + l of dx16 —
- * the zero-padded [B, Lp, C] operand of the Conv1d gradient products (pads are the caller's). */
+ * the zero-padded [B, Lp, C] operand of the Conv1d gradient products (pads are the caller's).
+ * dy_bf16 != 0: dy points at a bf16 matrix (lddy in elements) — the input gradient of a 1x1 conv
+ * written by ac_gemm's c16 output; same C restriction. */
 
 /* ------------------------------------------------------------------------
  * Elementwise / reduction helpers.

@@ -770,3 +770,35 @@ def test_bf16_parameter_mirrors(dev, bf16_mode):
     assert torch.equal(H.cast16_wT(w), w.detach().t().contiguous().bfloat16())
     plain = torch.randn(8, 16, device=dev)                             # not a flattened parameter
     assert torch.equal(H.cast16_w(plain), plain.bfloat16())
+
+
+def test_conv_bank_bf16_handover(dev, bf16_mode):
+    """Pooled SpectraNet block in bf16 mode: LN+GELU output and the gradient coming back cross the
+    conv bank / 1x1 conv boundary in bf16 only (fp32 placeholders are never written).  Same forward as
+    the fp32 hand-over; gradients differ by one bf16 rounding of d(LN output)."""
+    from applecider_amd import hipops as H
+    B, L, Cin, Cout, ks = 3, 256, 64, 64, (3, 15, 31)
+    x = g(dev, B, L, Cin, seed=1)
+    ws = [g(dev, Cout, k * Cin, seed=10 + i) / math.sqrt(Cin * k) for i, k in enumerate(ks)]
+    bs = [g(dev, Cout, seed=20 + i) for i in range(3)]
+    gam, bet = 1 + 0.1 * g(dev, 3 * Cout, seed=30), 0.1 * g(dev, 3 * Cout, seed=31)
+    wd, bd = g(dev, Cout, 3 * Cout, seed=40) / 14, g(dev, Cout, seed=41)
+    go = g(dev, B, L, Cout, seed=50).to(dev)
+    t = lambda a: a.detach().to(dev).requires_grad_()
+
+    def run(only16):
+        leaves = [t(x)] + [t(w) for w in ws] + [t(b) for b in bs] + [t(gam), t(bet), t(wd), t(bd)]
+        xd, w3, b3, (gd, btd, wdd, bdd) = leaves[0], leaves[1:4], leaves[4:7], leaves[7:]
+        y = H.conv_group1d(xd, ks, w3, b3, ln=(gd, btd, 1e-5), out16_only=only16)
+        assert H._is16only(y) == only16
+        if only16:
+            with pytest.raises(RuntimeError):
+                H.add(y, y)                      # any other consumer of the placeholder is refused
+        z = H.linear(y, wdd, bdd)
+        z.backward(go)
+        return [z.detach()] + [l.grad for l in leaves]
+
+    a, b = run(True), run(False)
+    close(a[0], b[0], tol=0, name="forward")
+    for i, (u, v) in enumerate(zip(a[1:], b[1:])):
+        close(u, v, tol=1e-2, name=f"grad{i}")
