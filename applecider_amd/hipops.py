@@ -38,8 +38,17 @@ def _lib_():
     return _lib.load()
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw HIP stream handle of torch's current stream.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (9 us, ~340 calls per training step); the raw getter is a
+    single C call.  One process drives one GPU, so the device index is looked up once."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def _is16only(t) -> bool:
