@@ -76,6 +76,8 @@ SIGNATURES = {
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
                          _P, _I64, _I32, _I32, _I32, _I32, _P],
+    "ac_mpt_mask": [_P, _P, _P, _I32, _I32, C.c_double, C.c_uint64, _P],
+    "ac_mpt_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _F, _F, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_colsum_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_cast_bf16_colsum": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P],

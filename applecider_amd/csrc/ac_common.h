@@ -89,7 +89,7 @@ __device__ __forceinline__ float ac_wave_max(float v) {
 // hash (two multiply-xorshift rounds, the murmur3 finaliser) of (seed, index) -> uniform in [0,1).
 // 32-bit arithmetic on purpose: inside a GEMM epilogue the generator runs at 2 waves per SIMD, and
 // a 64-bit splitmix (three 64x64 multiplies = ~30 VALU ops per element) cost more than the product.
-__device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
+__device__ __forceinline__ unsigned ac_hash32(uint64_t seed, uint64_t idx) {
     unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x85EBCA77u;
     h ^= (unsigned)seed;
     h ^= h >> 16;
@@ -98,7 +98,10 @@ __device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
     h ^= h >> 13;
     h *= 0xC2B2AE35u;
     h ^= h >> 16;
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
+    return h;
+}
+__device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
+    return (float)(ac_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ int64_t ac_rowaddr(const ac_rowmap &m, int r) {

@@ -240,6 +240,153 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Masked pre-training (MPTModel.train_step, HyraxBaselineCLS.py:226-319).
+// mpt_mask_kernel: the selection of _mask_batch (:286-319) on the device, one workgroup per light
+// curve: k = max(int(n_valid * mask_p), 3) tokens, k/3 per band (fewer when a band is short), the
+// remainder from whatever valid tokens are left; channels 2..6 of the selected tokens are zeroed in
+// place and the selection is returned.  Random choices are partial Fisher-Yates draws from the
+// counter hash (the reference's torch.randperm stream cannot be reproduced; counts and
+// eligibility are what the tests pin).
+// ---------------------------------------------------------------------------------------------
+constexpr int MPT_MAXL = 2048;
+
+__global__ __launch_bounds__(64) void mpt_mask_kernel(float *__restrict__ x,
+                                                      const uint8_t *__restrict__ pad,
+                                                      uint8_t *__restrict__ masked, int L,
+                                                      double mask_p, uint64_t seed) {
+    __shared__ unsigned short lst[MPT_MAXL];
+    __shared__ unsigned char sel[MPT_MAXL], band[MPT_MAXL];
+    const int b = blockIdx.x;
+    float *xb = x + (int64_t)b * L * 7;
+    const uint8_t *pb = pad + (int64_t)b * L;
+    for (int l = threadIdx.x; l < L; l += 64) {
+        sel[l] = 0;
+        const float x4 = xb[l * 7 + 4], x5 = xb[l * 7 + 5], x6 = xb[l * 7 + 6];
+        int bd = 0;                       // argmax, first maximum wins
+        if (x5 > x4) bd = 1;
+        if (x6 > (x5 > x4 ? x5 : x4)) bd = 2;
+        band[l] = pb[l] ? 255 : bd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nvalid = 0;
+        for (int l = 0; l < L; ++l) nvalid += band[l] != 255;
+        int k = (int)((double)nvalid * mask_p);
+        k = k > 3 ? k : 3;
+        const int num_each = k / 3, extras = k - 3 * num_each;
+        uint64_t ctr = (uint64_t)b << 20;
+        auto draw = [&](int n, int take) {
+            take = take < n ? take : n;
+            for (int i = 0; i < take; ++i) {
+                const int j = i + (int)(((uint64_t)ac_hash32(seed, ctr++) * (uint64_t)(n - i)) >> 32);
+                const unsigned short tmp = lst[i];
+                lst[i] = lst[j];
+                lst[j] = tmp;
+                sel[lst[i]] = 1;
+            }
+        };
+        for (int bd = 0; bd < 3; ++bd) {
+            int n = 0;
+            for (int l = 0; l < L; ++l)
+                if (band[l] == bd) lst[n++] = (unsigned short)l;
+            draw(n, num_each);
+        }
+        if (extras > 0) {
+            int n = 0;
+            for (int l = 0; l < L; ++l)
+                if (band[l] != 255 && !sel[l]) lst[n++] = (unsigned short)l;
+            draw(n, extras);
+        }
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += 64) {
+        masked[(int64_t)b * L + l] = sel[l];
+        if (sel[l]) {
+#pragma unroll
+            for (int c = 2; c < 7; ++c) xb[l * 7 + c] = 0.f;
+        }
+    }
+}
+
+// Three-term product loss over the selected tokens (:258-278): sums first, then loss and gradients.
+// Head outputs carry the CLS row (token 0) of the encoder output; it gets a zero gradient.
+__device__ __forceinline__ void mpt_terms(const float *f_hat, const float *b_hat, const float *dt_hat,
+                                          const float *data, int b, int l, int L, float &ef,
+                                          float &edt, float (&p)[3], int &tb, float &ce) {
+    const int64_t tok = (int64_t)b * (L + 1) + l + 1;
+    const float *d = data + ((int64_t)b * L + l) * 7;
+    ef = f_hat[tok] - d[2];
+    const float x4 = d[4], x5 = d[5], x6 = d[6];
+    tb = 0;
+    if (x5 > x4) tb = 1;
+    if (x6 > (x5 > x4 ? x5 : x4)) tb = 2;
+    const float gt = (l + 1 < L) ? d[7 + 1] : 0.f;   // roll(dt_prev, -1) with the last entry zeroed
+    edt = dt_hat[tok] - gt;
+    const float z0 = b_hat[tok * 3], z1 = b_hat[tok * 3 + 1], z2 = b_hat[tok * 3 + 2];
+    const float m = fmaxf(z0, fmaxf(z1, z2));
+    const float e0 = __expf(z0 - m), e1 = __expf(z1 - m), e2 = __expf(z2 - m);
+    const float s = e0 + e1 + e2;
+    p[0] = e0 / s; p[1] = e1 / s; p[2] = e2 / s;
+    ce = -(((tb == 0 ? z0 : (tb == 1 ? z1 : z2)) - m) - __logf(s));
+}
+
+__global__ __launch_bounds__(256) void mpt_loss_sums_kernel(const float *f_hat, const float *b_hat,
+                                                            const float *dt_hat, const float *data,
+                                                            const uint8_t *masked, float *sums,
+                                                            int B, int L) {
+    __shared__ float red[4][4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int64_t n = (int64_t)B * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (!masked[i]) continue;
+        float ef, edt, p[3], ce;
+        int tb;
+        mpt_terms(f_hat, b_hat, dt_hat, data, (int)(i / L), (int)(i % L), L, ef, edt, p, tb, ce);
+        a0 += ef * ef; a1 += ce; a2 += edt * edt; a3 += 1.f;
+    }
+    a0 = ac_wave_sum(a0); a1 = ac_wave_sum(a1); a2 = ac_wave_sum(a2); a3 = ac_wave_sum(a3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a0; red[1][w] = a1; red[2][w] = a2; red[3][w] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        atomicAdd(&sums[q], (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void mpt_loss_grad_kernel(const float *f_hat, const float *b_hat,
+                                                            const float *dt_hat, const float *data,
+                                                            const uint8_t *masked, const float *sums,
+                                                            float *loss, float *df, float *db,
+                                                            float *ddt, int B, int L, float lf_w,
+                                                            float lb_w, float ldt_w) {
+    const float cnt = sums[3];
+    const float lf = sums[0] / cnt, lb = sums[1] / cnt, ldt = sums[2] / cnt;   // empty selection: NaN, as torch
+    const float c = lf_w * lb_w * ldt_w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) loss[0] = c * lf * lb * ldt;
+    const int T = L + 1;
+    const int64_t n = (int64_t)B * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        float gf = 0.f, gdt = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (t > 0 && masked[(int64_t)b * L + t - 1]) {
+            float ef, edt, p[3], ce;
+            int tb;
+            mpt_terms(f_hat, b_hat, dt_hat, data, b, t - 1, L, ef, edt, p, tb, ce);
+            gf = c * lb * ldt * 2.f * ef / cnt;
+            gdt = c * lf * lb * 2.f * edt / cnt;
+            const float s = c * lf * ldt / cnt;
+            g0 = s * (p[0] - (tb == 0 ? 1.f : 0.f));
+            g1 = s * (p[1] - (tb == 1 ? 1.f : 0.f));
+            g2 = s * (p[2] - (tb == 2 ? 1.f : 0.f));
+        }
+        df[i] = gf;
+        ddt[i] = gdt;
+        db[i * 3] = g0; db[i * 3 + 1] = g1; db[i * 3 + 2] = g2;
+    }
+}
+
 }  // namespace
 
 extern "C" int ac_embed_fwd(const float *x, const float *W, const float *bias, const float *tw,
@@ -307,6 +454,38 @@ extern "C" int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pa
                            pad, out, lse, dqkv, T, H, p_drop, seed);
     else
         return AC_EINVAL;
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_mpt_mask(float *x, const uint8_t *pad, uint8_t *masked, int32_t B, int32_t L,
+                           double mask_p, uint64_t seed, ac_stream_t stream) {
+    if (!x || !pad || !masked || B <= 0 || L <= 0 || L > MPT_MAXL || mask_p < 0.0 || mask_p > 1.0)
+        return AC_EINVAL;
+    hipLaunchKernelGGL(mpt_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, pad, masked, L,
+                       mask_p, seed);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_mpt_loss_fwd_bwd(const float *f_hat, const float *b_hat, const float *dt_hat,
+                                   const float *data, const uint8_t *masked, float *sums, float *loss,
+                                   float *df, float *db, float *ddt, int32_t B, int32_t L,
+                                   float lambda_f, float lambda_b, float lambda_dt,
+                                   ac_stream_t stream_) {
+    if (!f_hat || !b_hat || !dt_hat || !data || !masked || !sums || !loss || !df || !db || !ddt ||
+        B <= 0 || L <= 0)
+        return AC_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(float), stream);
+    if (e != hipSuccess) return -(int)e - 2000;
+    const int64_t n = (int64_t)B * (L + 1);
+    int grid = (int)((n + 255) / 256);
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL(mpt_loss_sums_kernel, dim3(grid), dim3(256), 0, stream, f_hat, b_hat, dt_hat, data,
+                       masked, sums, B, L);
+    hipLaunchKernelGGL(mpt_loss_grad_kernel, dim3(grid), dim3(256), 0, stream, f_hat, b_hat, dt_hat, data,
+                       masked, sums, loss, df, db, ddt, B, L, lambda_f, lambda_b, lambda_dt);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

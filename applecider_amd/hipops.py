@@ -1536,3 +1536,56 @@ def pad_channels(x: torch.Tensor, width: int) -> torch.Tensor:
     out = torch.zeros(*x.shape[:-1], width, device=x.device, dtype=torch.float32)
     _lib.check(_lib_().ac_copy2d(_p(x), Cn, _p(out), width, rows, Cn, _stream()), "ac_copy2d")
     return out
+
+
+# --------------------------------------------------------------------------- masked pre-training
+def mpt_mask(data: torch.Tensor, pad: torch.Tensor, mask_p: float, seed: Optional[int] = None):
+    """MPTModel._mask_batch on the device (HyraxBaselineCLS.py:286-319): zeroes channels 2..6 of the
+    selected tokens of `data` IN PLACE and returns the selection as a bool tensor."""
+    data = _chk(data, "data")
+    B, L, Cn = data.shape
+    if Cn != 7:
+        raise ValueError("photometry tokens must have 7 channels")
+    pad_u8 = pad.to(torch.uint8).contiguous()
+    masked = torch.empty(B, L, device=data.device, dtype=torch.uint8)
+    _lib.check(_lib_().ac_mpt_mask(_p(data), _p(pad_u8), _p(masked), B, L, float(mask_p),
+                                   next_seed() if seed is None else int(seed), _stream()), "ac_mpt_mask")
+    return masked.bool()
+
+
+class _MPTLoss(Function):
+    """Three-term product loss of MPTModel.train_step (HyraxBaselineCLS.py:258-278); loss and the
+    gradients of the three head outputs in one pass over the tokens."""
+
+    @staticmethod
+    def forward(ctx, f_hat, b_hat, dt_hat, data, masked_u8, lambdas):
+        f_hat, b_hat, dt_hat = _chk(f_hat, "f_hat"), _chk(b_hat, "b_hat"), _chk(dt_hat, "dt_hat")
+        data = _chk(data, "data")
+        B, L, _ = data.shape
+        dev = data.device
+        if f_hat.numel() != B * (L + 1) or b_hat.numel() != 3 * B * (L + 1):
+            raise ValueError("head outputs must cover the whole encoder output [B, L+1, .]")
+        sums = torch.empty(4, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        df, db, ddt = torch.empty_like(f_hat), torch.empty_like(b_hat), torch.empty_like(dt_hat)
+        _lib.check(_lib_().ac_mpt_loss_fwd_bwd(_p(f_hat), _p(b_hat), _p(dt_hat), _p(data), _p(masked_u8),
+                                               _p(sums), _p(loss), _p(df), _p(db), _p(ddt), B, L,
+                                               float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
+                                               _stream()), "ac_mpt_loss_fwd_bwd")
+        ctx.save_for_backward(df, db, ddt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        df, db, ddt = ctx.saved_tensors
+        if g.numel() == 1 and not g.requires_grad:
+            # upstream gradient of a scalar loss: scale on the device, no host sync
+            gs = g.reshape(1).to(torch.float32)
+            lib, st = _lib_(), _stream()
+            for t in (df, db, ddt):
+                _lib.check(lib.ac_scale_by_dev(_p(t), t.numel(), _p(gs), st), "ac_scale_by_dev")
+        return df, db, ddt, None, None, None
+
+
+def mpt_loss(f_hat, b_hat, dt_hat, data, masked: torch.Tensor, lambdas):
+    return _MPTLoss.apply(f_hat, b_hat, dt_hat, data, masked.to(torch.uint8).contiguous(), tuple(lambdas))

@@ -107,8 +107,9 @@ class HyraxBaselineCLS(nn.Module):
 class MPTModel(nn.Module):
     """Masked-pretraining model (HyraxBaselineCLS.py:194-364): same encoder stack plus flux / band /
     dt heads.  Constructor, `forward(z)` (the three heads), `to_tensor` and the state_dict follow the
-    reference; the masked pre-training `train_step` (per-band random masking + the three-term product
-    loss, :226-284) is the next row of SURVEY §8f and is not on the MI355X path yet."""
+    reference; `train_step` is the masked pre-training step (:226-284): per-band random masking on the
+    device (`ac_mpt_mask`), the encoder kernels of HyraxBaselineCLS, and the three-term product loss
+    with its gradients in one pass (`ac_mpt_loss_fwd_bwd`)."""
 
     def __init__(self, config, data_sample=None):
         super().__init__()
@@ -132,8 +133,39 @@ class MPTModel(nn.Module):
         h = embed_tokens(self.in_proj, self.time2vec, self.cls_tok, data)
         return self.encoder(h, extend_pad_mask(pad))
 
+    def _mask_batch(self, x, pad_mask, seed=None):
+        """Per-band random masking on the device (HyraxBaselineCLS.py:286-319): modifies `x` in place
+        and returns the selection, as the reference's method does."""
+        return H.mpt_mask(x, pad_mask, self.config["model"]["HyraxBaselineCLS"]["mask_p"], seed)
+
+    def pretrain_loss(self, data, pad, masked):
+        """Forward of the pre-training step for an already masked batch (:232-278)."""
+        mc = self.config["model"]["HyraxBaselineCLS"]
+        B, L, _ = data.shape
+        x8 = H.pad_channels(data, 8)
+        zero_d = torch.zeros(self.time2vec.d_model, device=data.device)
+        # [cls ; in_proj(x)] and [0 ; time2vec(t)] as two embed launches: the reference drops out the
+        # time embedding alone (F.dropout(te, p), always active in this step, :243)
+        emb = H.embed(x8, self.in_proj.weight, self.in_proj.bias, zero_d, zero_d, self.cls_tok.reshape(-1))
+        te = H.embed(x8, torch.zeros_like(self.in_proj.weight), zero_d, self.time2vec.tw,
+                     self.time2vec.tb, zero_d)
+        h = H.add(emb, H.dropout(te, mc["dropout"], True))
+        z = self.encoder(h, extend_pad_mask(pad))              # [B, L+1, d]
+        f_hat, b_hat, dt_hat = self.head_flux(z), self.head_band(z), self.head_dt(z)
+        return H.mpt_loss(f_hat, b_hat, dt_hat, data, masked,
+                          (mc["lambda_f"], mc["lambda_b"], mc["lambda_dt"]))
+
     def train_step(self, batch):
-        raise NotImplementedError("MPTModel.train_step (masked pre-training) is not built on the "
-                                  "MI355X path yet; see DESIGN.md section 7")
+        """Masked pre-training step (:226-284): mask -> encode -> three heads -> product loss ->
+        backward -> clip_grad_norm_(1.0) -> AdamW.  `batch[0]` is modified in place by the masking,
+        as in the reference."""
+        data, pad = batch[0], batch[1]
+        masked = self._mask_batch(data, pad)
+        self.optimizer.zero_grad()
+        loss = self.pretrain_loss(data, pad, masked)
+        loss.backward()
+        self.optimizer.clip_grad_norm_(1.0)
+        self.optimizer.step()
+        return {"loss": loss.item()}
 
     to_tensor = staticmethod(HyraxBaselineCLS.to_tensor)

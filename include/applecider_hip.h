@@ -337,6 +337,25 @@ int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha,
                     ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Masked pre-training step of MPTModel (HyraxBaselineCLS.py:226-319).
+ * ac_mpt_mask: _mask_batch (:286-319) on the device.  x [B, L, 7] (in place: channels 2..6 of the
+ * selected tokens become 0), pad [B, L] (1 = padding), masked [B, L] out.  Per light curve
+ * k = max(int(n_valid * mask_p), 3) tokens: k/3 from each band (argmax of channels 4..6), the
+ * remainder from the valid tokens still unselected; draws come from the counter hash of `seed`.
+ * ac_mpt_loss_fwd_bwd: loss = lambda_f*MSE(f_hat, x[...,2]) * lambda_b*CE(b_hat, argmax x[...,4:7])
+ * * lambda_dt*MSE(dt_hat, roll(x[...,1], -1) with a zero last entry), each a mean over the selected
+ * tokens, targets read from the MASKED x exactly as the reference does (:262-271).  f_hat / dt_hat
+ * [B, L+1], b_hat [B, L+1, 3] are the heads applied to the whole encoder output (token 0 = CLS, zero
+ * gradient); outputs: loss (1 float), df, db, ddt in the same shapes.  sums: 4 floats of scratch.
+ * ---------------------------------------------------------------------- */
+int ac_mpt_mask(float *x, const uint8_t *pad, uint8_t *masked, int32_t B, int32_t L, double mask_p,
+                uint64_t seed, ac_stream_t stream);
+int ac_mpt_loss_fwd_bwd(const float *f_hat, const float *b_hat, const float *dt_hat,
+                        const float *data, const uint8_t *masked, float *sums, float *loss, float *df,
+                        float *db, float *ddt, int32_t B, int32_t L, float lambda_f, float lambda_b,
+                        float lambda_dt, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Optimizers over flat fp32 buffers (torch.optim.AdamW astrominn.py:151-218,
  * Adam HyraxBaselineCLS.py:41, SGD injected by Hyrax for SpectraNet).
  * seg_* describe param groups as [begin,end) element ranges with their own

@@ -185,6 +185,38 @@ def baselinecls_forward(sd, data, pad, n_heads=8, n_layers=4, classification=Tru
     return out
 
 
+def mpt_apply_mask(data, masked):
+    """The in-place effect of MPTModel._mask_batch for a GIVEN selection (HyraxBaselineCLS.py:316-318):
+    channels 2..6 (logf, logfe, band one-hot) of the selected tokens are zeroed."""
+    data = data.clone()
+    data[masked] = torch.cat([data[masked][:, :2], torch.zeros_like(data[masked][:, 2:])], 1)
+    return data
+
+
+def mpt_loss(sd, data, pad, masked, n_heads=8, n_layers=4, lambdas=(1.0, 1.0, 1.0)):
+    """MPTModel.train_step up to the loss (HyraxBaselineCLS.py:226-278) for a given mask and dropout 0.
+    `data` is the tensor AFTER masking — the reference reads its regression / band targets from the
+    tensor it has just zeroed (:262-266), so at the masked tokens true_f = 0 and true_b = argmax(0,0,0)
+    = 0; that behaviour is reproduced, not corrected.  Returns (loss, loss_f, loss_b, loss_dt)."""
+    B = data.shape[0]
+    h = _lin(sd, "in_proj", data) + time2vec(sd, "time2vec", data[..., 0])
+    h = torch.cat([sd["cls_tok"].expand(B, -1, -1), h], 1)
+    pad_ext = torch.cat([pad.new_zeros((B, 1)), pad], 1)
+    for i in range(n_layers):
+        h = encoder_layer(sd, f"encoder.layers.{i}", h, pad_ext, n_heads)
+    z = h[:, 1:, :]
+    f_hat, b_hat, dt_hat = _lin(sd, "head_flux", z), _lin(sd, "head_band", z), _lin(sd, "head_dt", z)
+    mf = masked.reshape(-1)
+    loss_f = F.mse_loss(f_hat.reshape(-1)[mf], data[..., 2].reshape(-1)[mf])
+    true_b = data[..., 4:7].argmax(-1).reshape(-1)
+    loss_b = F.cross_entropy(b_hat.reshape(-1, 3)[mf], true_b[mf])
+    dt_gt = torch.roll(data[..., 1], -1, dims=1).clone()
+    dt_gt[:, -1] = 0.0
+    loss_dt = F.mse_loss(dt_hat[..., 0].reshape(-1)[mf], dt_gt.reshape(-1)[mf])
+    lf, lb, ldt = lambdas
+    return lf * loss_f * lb * loss_b * ldt * loss_dt, loss_f, loss_b, loss_dt
+
+
 def focal_loss(logits, target, gamma=2.0, alpha=None, eps=0.0):
     """FocalLoss.forward, reduction='mean' (HyraxBaselineCLS.py:169-191)."""
     C = logits.shape[1]

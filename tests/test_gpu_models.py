@@ -241,3 +241,92 @@ def test_applecider_train_step_bf16_runs(dev):
     finally:
         H.set_math("f32")
     assert np.isfinite(l)
+
+
+# ----------------------------------------------------------------------------- masked pre-training
+def _mpt_inputs():
+    from applecider_amd.synthetic import make_batch
+    L = 128
+    b = make_batch(4, seed=9, L=L)
+    pad = np.arange(L)[None, :] >= np.array([L, 90, 11, 40])[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    return data, pad
+
+
+def test_mpt_train_step_golden(dev):
+    """MPTModel.train_step against the reference's own step (g9: dropout 0, its random selection
+    replaced by a fixed mask): loss, gradients before clipping, parameters after clip + AdamW."""
+    from applecider_amd.models.HyraxBaselineCLS import MPTModel
+    g = gold("g9_mpt.npz")
+    data, pad = _mpt_inputs()
+    cfg = cfg_default()
+    cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0})
+    m = build(MPTModel, cfg, dev).train()
+    masked = T(g["masked"]).to(dev)
+
+    def fixed_mask(x, pad_mask, seed=None):
+        x[masked] = torch.cat([x[masked][:, :2], torch.zeros_like(x[masked][:, 2:])], 1)
+        return masked
+    m._mask_batch = fixed_mask
+    res = m.train_step((T(data.copy()).to(dev), T(pad).to(dev), None))
+    ref = float(g["loss"])
+    assert abs(res["loss"] - ref) <= LOGIT_TOL * abs(ref), (res["loss"], ref)
+    gr = grads_by_ref_name(m)      # the flat gradient buffer keeps the unclipped gradients
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("after_step."):
+            assert_close(compact(sd[k[11:]].detach().cpu().numpy()), g[k], 1e-4, k)
+
+
+def test_mpt_mask_kernel(dev):
+    """Device-side _mask_batch: the counts and eligibility rules of HyraxBaselineCLS.py:286-319."""
+    from applecider_amd import hipops as H
+    from applecider_amd.synthetic import make_batch
+    B, L, p = 64, 128, 0.30
+    b = make_batch(B, seed=3, L=L)
+    data0 = T(b["photometry"])
+    pad = T(b["pad_mask"]).clone()
+    pad[0] = True                      # an empty light curve: nothing may be selected
+    pad[1, 2:] = True                  # two valid tokens: k = 3, at most one per band
+    data = data0.clone().to(dev)
+    masked = H.mpt_mask(data, pad.to(dev), p, seed=1234).cpu()
+    data = data.cpu()
+    assert not masked[pad].any()
+    band = data0[..., 4:7].argmax(-1)
+    for i in range(B):
+        valid = ~pad[i]
+        n = int(valid.sum())
+        k = max(int(n * p), 3)
+        each, extras = k // 3, k - 3 * (k // 3)
+        per_band = [int((masked[i] & (band[i] == j)).sum()) for j in range(3)]
+        avail = [int((valid & (band[i] == j)).sum()) for j in range(3)]
+        base = [min(a, each) for a in avail]
+        total = int(masked[i].sum())
+        assert total == min(n, sum(base) + min(extras, n - sum(base))), (i, total, base, extras, n)
+        assert all(pb >= bs for pb, bs in zip(per_band, base))
+    sel = masked
+    assert torch.equal(data[sel][:, 2:], torch.zeros_like(data[sel][:, 2:]))
+    assert torch.equal(data[sel][:, :2], data0[sel][:, :2])
+    assert torch.equal(data[~sel], data0[~sel])
+    # a different seed picks different tokens; the same seed the same ones
+    d2 = data0.clone().to(dev)
+    again = H.mpt_mask(d2, pad.to(dev), p, seed=1234).cpu()
+    other = H.mpt_mask(data0.clone().to(dev), pad.to(dev), p, seed=99).cpu()
+    assert torch.equal(again, masked) and not torch.equal(other, masked)
+    # positions are spread over the light curve (no prefix bias)
+    pos = masked[2:].float().sum(0)
+    assert pos[:8].sum() < 0.3 * pos.sum()
+
+
+def test_mpt_train_step_runs_with_dropout(dev):
+    from applecider_amd.models.HyraxBaselineCLS import MPTModel
+    from applecider_amd.synthetic import make_batch
+    m = build(MPTModel, cfg_default(), dev).train()
+    b = make_batch(16, seed=8, L=64)
+    l0 = m.train_step((T(b["photometry"]).to(dev), T(b["pad_mask"]).to(dev), None))["loss"]
+    l1 = m.train_step((T(b["photometry"]).to(dev), T(b["pad_mask"]).to(dev), None))["loss"]
+    assert np.isfinite(l0) and np.isfinite(l1)

@@ -114,6 +114,37 @@ def test_g5_baselinecls_oracle(L):
                     assert_close(sd[k[len(f"L{L}.grad."):]].grad, g[k], 2e-4, k)
 
 
+def _mpt_inputs():
+    from applecider_amd.synthetic import make_batch
+    L = 128
+    b = make_batch(4, seed=9, L=L)
+    pad = np.arange(L)[None, :] >= np.array([L, 90, 11, 40])[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    return data, pad
+
+
+def test_g9_mpt_oracle():
+    """Masked pre-training loss (MPTModel.train_step) restated for a given mask, against the reference's
+    own step with its random selection replaced by that mask (tools/make_goldens.py g9_mpt)."""
+    from applecider_amd.models.HyraxBaselineCLS import MPTModel
+    from oracle import functional as O
+    g = gold("g9_mpt.npz")
+    data, pad = _mpt_inputs()
+    cfg = cfg_default()
+    cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0})
+    mc = cfg["model"]["HyraxBaselineCLS"]
+    sd = {k: v.requires_grad_() for k, v in closed_form_sd(MPTModel(cfg)).items()}
+    masked = T(g["masked"])
+    x = O.mpt_apply_mask(T(data), masked)
+    loss, lf, lb, ldt = O.mpt_loss(sd, x, T(pad), masked, lambdas=(mc["lambda_f"], mc["lambda_b"], mc["lambda_dt"]))
+    assert_close(loss, g["loss"], 5e-5, "loss")
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(sd[k[5:]].grad.numpy()), g[k], 3e-4, k)
+
+
 def test_g6_focal_time2vec():
     from oracle import functional as O
     from oracle.weights import closed_form_state_dict
