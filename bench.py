@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="development only: run the N > 1 code path with every rank on cuda:0 over gloo "
+                         "(a one-GPU box cannot host an RCCL communicator with two ranks)")
     args = ap.parse_args()
 
     from applecider_amd import ddp, hipops as H
@@ -153,7 +156,11 @@ def main():
     from applecider_amd.models.applecider import AppleCider
     from applecider_amd.synthetic import make_batch
 
-    rank, local, world = ddp.init_from_env()
+    if args.rehearse_one_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+        rank, local, world = ddp.init_from_env(backend="gloo")
+    else:
+        rank, local, world = ddp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device(f"cuda:{local}")
