@@ -878,6 +878,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
             lb.template load<BG, FS>(kt + 2, rb1, mb1);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ahead of the MFMA phase
             compute(S0, S0 + Cfg::A_TILE);
+            // NT: the mask + LDS store of the prefetched registers (and the vmcnt waits in front of
+            // them) must not be hoisted between the MFMAs — hipcc otherwise gates MFMA #1 on a load
+            // issued only half an iteration earlier (+5 % on 8192x8192x4096; the TN loop, whose
+            // fragment reads are twice as many, measured 4 % slower with the pin and keeps hipcc's order)
+            if constexpr (!TN) __builtin_amdgcn_sched_barrier(0);
             la.store(S1, ra0, ma0);
             lb.store(S1 + Cfg::A_TILE, rb0, mb0);
             __syncthreads();
@@ -886,6 +891,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
             lb.template load<BG, FS>(kt + 3, rb0, mb0);
             __builtin_amdgcn_sched_barrier(0);
             compute(S1, S1 + Cfg::A_TILE);
+            if constexpr (!TN) __builtin_amdgcn_sched_barrier(0);
             la.store(S0, ra1, ma1);
             lb.store(S0 + Cfg::A_TILE, rb1, mb1);
             __syncthreads();
