@@ -79,6 +79,11 @@ class GradBuckets:
         self.launched[b] = True
         lo, hi = self.buckets[b]
         view = self.fp.grad[lo:hi]
+        if view.is_cuda:
+            # a bucket mixes parameters of branches that run on different streams: the collective
+            # (which orders itself after the CURRENT stream only) must see all their gradients
+            from . import hipops as H
+            H.wait_side_streams()
         self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
                                             async_op=True))
 

@@ -220,6 +220,40 @@ def _mirror(w, transposed: bool):
     return fp.flat16[off:off + n].view(w.shape)
 
 
+# Side streams on which model branches run (models/applecider.py).  Whoever consumes gradients
+# outside autograd's own stream bookkeeping (the DDP bucket launcher) must order itself after them.
+_side_streams: list = []
+
+
+def register_side_streams(streams):
+    for st in streams:
+        if all(st is not r for r in _side_streams):
+            _side_streams.append(st)
+
+
+def wait_side_streams():
+    """Make the current stream wait for everything queued so far on the registered side streams."""
+    if not _side_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for st in _side_streams:
+        if st != cur and st.device == cur.device:
+            cur.wait_stream(st)
+
+
+def ensure_mirrors(fp):
+    """Refresh the bf16 parameter mirrors now (on the current stream) if they are stale: callers that
+    fan work out over several streams do this before the fork, so that no branch triggers the lazy
+    refresh while another is already reading the mirrors."""
+    if fp is None or fp.flat is None or not fp.flat.is_cuda or not bf16_operands():
+        return
+    stale = fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
+    if not stale:
+        stale = any(v != p._version for v, p in zip(fp.mirror_pver, fp.params))
+    if stale:
+        fp.refresh_mirrors()
+
+
 def cast16_w(w):
     """bf16 copy of a weight, computed once per optimizer step."""
     m = _mirror(w, False)

@@ -61,11 +61,41 @@ class AppleCider(nn.Module):
                                   betas=(config.get("beta1", 0.9), config.get("beta2", 0.999)),
                                   weight_decay=config.get("weight_decay", 0.0))
 
+    # The three encoders are independent until the fusion head.  Each runs on its own HIP stream
+    # (forked from / joined to the caller's stream with events), so the small launches of the image
+    # and photometry branches (108-workgroup products, row kernels) fill the CUs that the tails of the
+    # spectra branch's large kernels leave idle.  autograd replays every backward node on the stream
+    # of its forward and synchronises at stream boundaries, so backward overlaps the same way.
+    branch_streams = True
+
+    def _streams(self, device):
+        st = getattr(self, "_branch_streams", None)
+        if st is None or st[0].device != device:
+            st = [torch.cuda.Stream(device=device) for _ in range(2)]
+            self._branch_streams = st
+            H.register_side_streams(st)
+        return st
+
     def get_embeddings(self, photometry, photometry_mask, metadata, images, spectra):
-        p_emb = self.photometry_proj(self.photometry_encoder((photometry, photometry_mask, None)))
-        s_emb = self.spectra_proj(self.spectra_encoder((spectra, None, None)))
-        im_emb = self.img_metadata_proj(self.img_metadata_encoder((metadata, images, None)))
-        return H.l2_normalize(p_emb), H.l2_normalize(im_emb), H.l2_normalize(s_emb)
+        if not (self.branch_streams and spectra.is_cuda):
+            p_emb = self.photometry_proj(self.photometry_encoder((photometry, photometry_mask, None)))
+            s_emb = self.spectra_proj(self.spectra_encoder((spectra, None, None)))
+            im_emb = self.img_metadata_proj(self.img_metadata_encoder((metadata, images, None)))
+            return H.l2_normalize(p_emb), H.l2_normalize(im_emb), H.l2_normalize(s_emb)
+        main = torch.cuda.current_stream(spectra.device)
+        s_img, s_pho = self._streams(spectra.device)
+        H.ensure_mirrors(self.optimizer.fp)          # bf16 weight copies are refreshed before the fork
+        for st in (s_img, s_pho):
+            st.wait_stream(main)
+        with torch.cuda.stream(s_img):
+            im_emb = H.l2_normalize(self.img_metadata_proj(self.img_metadata_encoder((metadata, images, None))))
+        with torch.cuda.stream(s_pho):
+            p_emb = H.l2_normalize(self.photometry_proj(self.photometry_encoder((photometry, photometry_mask, None))))
+        s_emb = H.l2_normalize(self.spectra_proj(self.spectra_encoder((spectra, None, None))))
+        for st, t in ((s_img, im_emb), (s_pho, p_emb)):
+            main.wait_stream(st)
+            t.record_stream(main)                    # allocated on a branch stream, consumed on `main`
+        return p_emb, im_emb, s_emb
 
     def forward(self, photometry, photometry_mask, metadata, images, spectra):
         p_emb, im_emb, s_emb = self.get_embeddings(photometry, photometry_mask, metadata, images, spectra)

@@ -20,21 +20,70 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(dev):
-    from common import cfg_default, closed_form_sd
-    from applecider_amd.models.astrominn import AstroMiNN
-    m = AstroMiNN(cfg_default())
-    m.load_state_dict(closed_form_sd(m))
-    return m.to(dev).eval()
+FUSED_CFG = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.0,
+             "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3}
 
 
-def _batch(seed, dev):
+class _Fused:
+    """The 4-modality model behind the interface the worker uses (its encoders run on three HIP
+    streams, so a gradient bucket mixes parameters whose backward kernels ran on different streams)."""
+
+    def __init__(self, dev):
+        from common import closed_form_sd
+        from applecider_amd.models.applecider import AppleCider
+        m = AppleCider(dict(FUSED_CFG))
+        m.load_state_dict(closed_form_sd(m))
+        self.m = m.to(dev).eval()
+        self.this_optimizer = self.m.optimizer
+
+    def named_parameters(self):
+        return self.m.named_parameters()
+
+    def loss(self, batch):
+        from applecider_amd import hipops as H
+        return H.cross_entropy_index(self.m(*batch[:5]), batch[5])
+
+
+class _Image:
+    def __init__(self, dev):
+        from common import cfg_default, closed_form_sd
+        from applecider_amd.models.astrominn import AstroMiNN
+        m = AstroMiNN(cfg_default())
+        m.load_state_dict(closed_form_sd(m))
+        self.m = m.to(dev).eval()
+        self.this_optimizer = self.m.this_optimizer
+
+    def named_parameters(self):
+        return self.m.named_parameters()
+
+    def loss(self, batch):
+        return self.m.this_criterion(self.m(batch), batch[2])
+
+
+def _make(dev, fused=False):
+    return _Fused(dev) if fused else _Image(dev)
+
+
+def _batch(seed, dev, fused=False):
     from applecider_amd.synthetic import make_batch
+    if fused:
+        b = make_batch(3, seed=seed)
+        return tuple(torch.from_numpy(b[k]).to(dev) for k in
+                     ("photometry", "pad_mask", "metadata", "image", "spectra", "label"))
     b = make_batch(8, seed=seed)
     return tuple(torch.from_numpy(b[k]).to(dev) for k in ("metadata", "image", "target"))
 
 
-def _worker(rank, world, port, q, overlap=True, sinks=True):
+def _worker(rank, world, port, q, overlap=True, sinks=True, fused=False):
+    try:
+        _worker_body(rank, world, port, q, overlap, sinks, fused)
+    except BaseException as e:  # the parent would otherwise sit in q.get() until its timeout
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, q, overlap, sinks, fused):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
@@ -46,17 +95,19 @@ def _worker(rank, world, port, q, overlap=True, sinks=True):
     ddp.init_from_env("gloo")
     from applecider_amd import hipops as H
     H.enable_grad_sinks(sinks)
-    m = _make(dev)
+    m = _make(dev, fused)
     opt = m.this_optimizer.prepare()
     ddp.broadcast_parameters(opt.fp)
     gb = ddp.GradBuckets(opt.fp, bucket_bytes=8 << 20, overlap=overlap)
     assert len(gb.buckets) > 3
-    batch = _batch(100 + rank, dev)
+    batch = _batch(100 + rank, dev, fused)
     opt.zero_grad()
-    loss = m.this_criterion(m(batch), batch[2])
+    loss = m.loss(batch)
     loss.backward()
-    # every parameter must have reported exactly one completed gradient before finish()
-    assert len(gb._seen) == len(opt.fp.params)
+    # every parameter must have reported exactly one completed gradient before finish() (the fused
+    # model owns parameters that are not on its path — e.g. the unused photometry class head — whose
+    # buckets are launched by finish())
+    assert len(gb._seen) == len(opt.fp.params) or fused
     gb.finish()
     torch.cuda.synchronize()
     q.put((rank, opt.fp.grad.cpu().numpy().copy(), float(loss.item())))
@@ -64,30 +115,33 @@ def _worker(rank, world, port, q, overlap=True, sinks=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,sinks", [(True, True), (False, True), (True, False)])
-def test_two_ranks_one_gpu_gradient_average(dev, overlap, sinks):
+@pytest.mark.parametrize("overlap,sinks,fused", [(True, True, False), (False, True, False), (True, False, False),
+                                                 (True, True, True)])
+def test_two_ranks_one_gpu_gradient_average(dev, overlap, sinks, fused):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap, sinks)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap, sinks, fused)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
     for _ in range(world):
-        rank, g, loss = q.get(timeout=300)
+        rank, g, loss = q.get(timeout=120)
+        assert g is not None, f"rank {rank} failed:\n{loss}"
         got[rank] = (g, loss)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     # single-process reference: gradient of each half-batch, averaged
-    m = _make(dev)
+    m = _make(dev, fused)
     opt = m.this_optimizer.prepare()
     ref = []
     for r in range(world):
-        batch = _batch(100 + r, dev)
+        batch = _batch(100 + r, dev, fused)
         opt.zero_grad()
-        m.this_criterion(m(batch), batch[2]).backward()
+        m.loss(batch).backward()
+        torch.cuda.synchronize()
         ref.append(opt.fp.grad.clone())
     want = ((ref[0] + ref[1]) / 2).cpu().numpy()
     scale = np.abs(want).max()
@@ -98,8 +152,9 @@ def test_two_ranks_one_gpu_gradient_average(dev, overlap, sinks):
         import bisect
         pi = bisect.bisect_right(opt.fp.offsets, i) - 1
         # the flat buffer is ordered by optimizer group, not by named_parameters(): report the offset
-        assert err.max() <= 1e-5 * scale, (f"rank {r}: max err {err.max():.3e} (scale {scale:.3e}) at flat "
+        tol = 2e-4 if fused else 1e-5   # fused: split-K atomics of the big conv products reorder sums
+        assert err.max() <= tol * scale, (f"rank {r}: max err {err.max():.3e} (scale {scale:.3e}) at flat "
                                            f"index {i}, param slot {pi} of {len(opt.fp.offsets)}, "
-                                           f"n_bad {(err > 1e-5 * scale).sum()}, local-vs-want "
+                                           f"n_bad {(err > tol * scale).sum()}, local-vs-want "
                                            f"{np.abs(ref[r].cpu().numpy() - want).max():.3e}")
     assert np.abs(got[0][0] - got[1][0]).max() == 0.0  # replicas hold identical averaged gradients
