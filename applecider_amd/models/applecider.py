@@ -71,6 +71,7 @@ class AppleCider(nn.Module):
     def _streams(self, device):
         st = getattr(self, "_branch_streams", None)
         if st is None or st[0].device != device:
+            # (stream priorities were tried for the side branches: no measurable effect)
             st = [torch.cuda.Stream(device=device) for _ in range(2)]
             self._branch_streams = st
             H.register_side_streams(st)
