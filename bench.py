@@ -11,8 +11,10 @@ on a synthetic batch of 512 samples per GPU already resident in HBM.  N > 1: one
 gradient buffer overlapped with backward.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with two extra objects:
-  roofline     dominant kernel family (largest summed launch time; HIP events around every launch in
-               the timed region).  Each launch is rated against the roof that bounds its shape
+  roofline     dominant kernel family (largest summed launch time; HIP events around every launch of a
+               roofline pass: 3 more steps right after the timed region with the encoders on one
+               stream, because overlapped kernels have no rate of their own and the events themselves
+               cost ~5 % of a step; --events-in-timed-region instruments the timed region as well).  Each launch is rated against the roof that bounds its shape
                (algorithmic FLOP / dense MFMA peak vs algorithmic bytes / HBM peak); the class holding
                more of the family's time is `roofline`, the other `roofline_other_class`.
   cpu_baseline the oracle (CPU restatement pinned to the reference) timed on this host's cores on a
@@ -146,6 +148,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--events-in-timed-region", action="store_true",
+                    help="also bracket every matrix-core launch of the TIMED region with HIP events (each "
+                         "event is a barrier packet in the queue: ~5 %% on the step, so off by default; the "
+                         "roofline pass that follows the timed region is always instrumented)")
     ap.add_argument("--no-branch-streams", action="store_true",
                     help="run the three encoders on one stream (the configuration the per-kernel "
                          "roofline pass and the committed rocprofv3 kernel statistics use)")
@@ -211,7 +217,7 @@ def main():
 
     torch.cuda.synchronize()
     barrier()
-    timer.enabled = True
+    timer.enabled = args.events_in_timed_region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -233,7 +239,8 @@ def main():
     # rates those launches; the overlapped sums of the timed region are kept beside them.  Every rank
     # takes part (the steps contain the gradient all-reduce).
     roof_steps, ran_pass = args.steps, False
-    if model.branch_streams:
+    was_streams = model.branch_streams
+    if model.branch_streams or not args.events_in_timed_region:
         roof_steps, ran_pass = min(args.steps, 3), True
         timer.records = {}
         model.branch_streams = False
@@ -243,7 +250,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         timer.enabled = False
-        model.branch_streams = True
+        model.branch_streams = was_streams
 
     if rank != 0:
         if world > 1:
@@ -308,7 +315,7 @@ def main():
     roofline["measured"] = (f"HIP events around every launch, {roof_steps} steps with the encoders on one stream "
                             "right after the timed region" if ran_pass
                             else "HIP events around every launch in the timed region (one stream)")
-    if ran_pass:
+    if ran_pass and args.events_in_timed_region:
         roofline["timed_region_overlapped"] = {
             k: {"launches": v["launches"], "sum_of_launch_ms_per_step": round(v["ms"] / timed_steps, 3)}
             for k, v in ks_timed.items() if k.startswith("gemm") or k.startswith("conv1d")}
