@@ -1149,6 +1149,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         const int tile = d.tile;  // 0 auto, 1 = 128x128, 2 = 256x64, 3 = 256x128 (8 waves)
         if (d.mode == AC_GEMM_TN) {
             if (tile == 3) return launch_bf16in<true, 4, 2>(p, stream);
+            if (tile == 4) return launch_bf16in<true, 2, 4>(p, stream);   // 128 x 256, 8 waves
             return launch_bf16in<true, 2, 2>(p, stream);
         }
         if (tile == 2 || (tile == 0 && d.N <= 64 && d.M >= 256)) return launch_bf16in<false, 4, 1>(p, stream);

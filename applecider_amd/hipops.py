@@ -337,6 +337,27 @@ def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     return split
 
 
+def _tn_plan(m_out: int, n_out: int, k_red: int):
+    """(tile, split_k) of a bf16 weight-gradient product.  Long reductions over a wide output use the
+    128 x 256 tile (8 waves, one workgroup per CU): per FLOP it pulls 25 % fewer operand bytes through
+    L2 than two 128 x 128 workgroups, which is what bounds these products (709 -> 860 TF on the stage-2
+    conv gradient).  Its split is chosen to land on a whole number of 256-workgroup rounds."""
+    nkt = -(-k_red // 64)
+    if n_out >= 1024 and m_out >= 128 and nkt >= 512:
+        tiles = -(-m_out // 128) * -(-n_out // 256)
+        best = None
+        for rounds in (1, 2, 4):
+            split = max(1, (256 * rounds) // tiles)
+            if nkt // split < 64:
+                continue
+            waste = (-(tiles * split) % 256) / 256.0 / max(1, -(-(tiles * split) // 256))
+            if best is None or waste < best[0] - 1e-9:
+                best = (waste, split)
+        if best is not None:
+            return 4, best[1]
+    return 0, _split_for(m_out, n_out, k_red)
+
+
 _seed_counter = itertools.count(1)
 
 
@@ -1355,10 +1376,10 @@ class _ConvGroup1d(Function):
                 wsink = _sink(ctx.params[0][j])
                 dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev,
                                                                   dtype=torch.float32)
+                tile_, split_ = _tn_plan(Cout, k * Cin, B * L) if b16 else (0, _split_for(Cout, k * Cin, B * L))
                 gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),
                      mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
-                     mat(_p(dw), k * Cin), accumulate=2, split_k=_split_for(Cout, k * Cin, B * L),
-                     math=mth)
+                     mat(_p(dw), k * Cin), accumulate=2, split_k=split_, tile=tile_, math=mth)
                 if wsink is not None:
                     dw = None
                     _grad_written(ctx.params[0][j])

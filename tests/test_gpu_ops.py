@@ -595,6 +595,33 @@ def test_gemm_bf16_operands(dev, M, N, K):
     assert torch.equal(c3.cpu(), ai @ bi.t())
 
 
+@pytest.mark.parametrize("tile", [3, 4])
+@pytest.mark.parametrize("M,N,K,split", [(128, 256, 640, 1), (200, 712, 520, 3), (384, 1032, 2048, 4)])
+def test_gemm_bf16_tn_wide_tiles(dev, tile, M, N, K, split):
+    """The 8-wave TN tiles (256 x 128 and 128 x 256, the latter used for the long Conv1d weight
+    gradients): exact integers, ragged edges, split-K atomics."""
+    from applecider_amd import hipops as H
+    ai = (torch.arange(M * K).reshape(M, K).remainder(7).float() - 3)
+    bi = (torch.arange(N * K).reshape(N, K).remainder(5).float() - 2)
+    c = torch.zeros(M, N, device=dev)
+    ait, bit = H.cast16_T(ai.to(dev)), H.cast16_T(bi.to(dev))   # [K, M], [K, N]
+    H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(ait), M), H.mat(H._p(bit), N), H.mat(H._p(c), N),
+           math=2, accumulate=2, split_k=split, tile=tile)
+    assert torch.equal(c.cpu(), ai @ bi.t())
+    # Toeplitz view as the B operand (the conv weight gradient): rows overlap by Cin elements
+    B_, L, Cin, k = 3, 64, 8, 32
+    Lp = L + k - 1
+    x = torch.randint(-3, 4, (B_, Lp, Cin)).float()
+    dy = torch.randint(-2, 3, (B_ * L, M)).float()
+    x16, dy16 = H.cast16(x.to(dev)), H.cast16(dy.to(dev))
+    dw = torch.zeros(M, k * Cin, device=dev)
+    H.gemm(H.AC_GEMM_TN, M, k * Cin, B_ * L, H.mat(H._p(dy16), M),
+           H.mat(H._p(x16), r1=L, r2=L, s1=Lp * Cin, s3=Cin), H.mat(H._p(dw), k * Cin),
+           math=2, accumulate=2, split_k=2, tile=tile)
+    win = x.unfold(1, k, 1).permute(0, 1, 3, 2).reshape(B_ * L, k * Cin)   # [B*L, (tap, ci)]
+    assert torch.equal(dw.cpu(), dy.t() @ win)
+
+
 @pytest.fixture
 def bf16_mode():
     from applecider_amd import hipops as H

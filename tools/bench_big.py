@@ -24,14 +24,14 @@ def plain(mode, M, N, K, split=1):
     ms = timeit(f)
     print(f"{mode} M{M} N{N} K{K} split{split}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TF", flush=True)
 
-def conv_dw(B, L, Cin, Cout, k, split):
+def conv_dw(B, L, Cin, Cout, k, split, tile=0):
     P = k // 2; Lp = L + 2 * P
     x16 = H.cast16(torch.randn(B, Lp, Cin, device=dev)); dy16 = H.cast16(torch.randn(B * L, Cout, device=dev))
     dw = torch.zeros(Cout, k * Cin, device=dev)
     f = lambda: H.gemm(2, Cout, k * Cin, B * L, H.mat(H._p(dy16), Cout), H.mat(H._p(x16), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
-                       H.mat(H._p(dw), k * Cin), accumulate=2, split_k=split, math=2)
+                       H.mat(H._p(dw), k * Cin), accumulate=2, split_k=split, math=2, tile=tile)
     ms = timeit(f, 3)
-    print(f"conv dW B{B} L{L} Cin{Cin} Cout{Cout} k{k} split{split}: {ms:.3f} ms  {2*B*L*Cout*k*Cin/ms/1e9:.1f} TF", flush=True)
+    print(f"conv dW B{B} L{L} Cin{Cin} Cout{Cout} k{k} split{split} tile{tile}: {ms:.3f} ms  {2*B*L*Cout*k*Cin/ms/1e9:.1f} TF", flush=True)
 
 def conv_fwd(B, L, Cin, Cout, k):
     P = k // 2; Lp = L + 2 * P
@@ -44,7 +44,12 @@ def conv_fwd(B, L, Cin, Cout, k):
 plain("NT", 8192, 8192, 4096)
 plain("TN", 4096, 4096, 8192)
 conv_dw(512, 1024, 64, 128, 251, 8)
+conv_dw(512, 1024, 64, 128, 251, 8, tile=4)
+conv_dw(512, 1024, 64, 128, 251, 4, tile=4)
+conv_dw(512, 1024, 64, 128, 251, 16, tile=4)
 conv_dw(512, 256, 128, 256, 61, 8)
+conv_dw(512, 256, 128, 256, 61, 8, tile=4)
+conv_dw(512, 256, 128, 256, 61, 16, tile=4)
 conv_fwd(512, 1024, 64, 128, 251)
 conv_fwd(512, 256, 128, 256, 61)
 plain("NT", 66048, 512, 128)
