@@ -608,6 +608,12 @@ def test_gemm_bf16_tn_wide_tiles(dev, tile, M, N, K, split):
     H.gemm(H.AC_GEMM_TN, M, N, K, H.mat(H._p(ait), M), H.mat(H._p(bit), N), H.mat(H._p(c), N),
            math=2, accumulate=2, split_k=split, tile=tile)
     assert torch.equal(c.cpu(), ai @ bi.t())
+    if tile == 3:   # the same tile shape on the NT side (long, wide products pick it automatically)
+        c_nt = torch.empty(M, N, device=dev)
+        a16, b16 = H.cast16(ai.to(dev)), H.cast16(bi.to(dev))
+        H.gemm(H.AC_GEMM_NT, M, N, K, H.mat(H._p(a16), K), H.mat(H._p(b16), K), H.mat(H._p(c_nt), N),
+               math=2, tile=3)
+        assert torch.equal(c_nt.cpu(), ai @ bi.t())
     # Toeplitz view as the B operand (the conv weight gradient): rows overlap by Cin elements
     B_, L, Cin, k = 3, 64, 8, 32
     Lp = L + k - 1
