@@ -73,6 +73,12 @@ class AppleCider(nn.Module):
         if st is None or st[0].device != device:
             # (stream priorities were tried for the side branches: no measurable effect)
             st = [torch.cuda.Stream(device=device) for _ in range(2)]
+            # parameters' AccumulateGrad nodes live on the stream of their first use; gradients now
+            # arrive from the branch streams.  autograd orders that with stream waits (what we want)
+            # and would warn about it on every step.
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
             self._branch_streams = st
             H.register_side_streams(st)
         return st
