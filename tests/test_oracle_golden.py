@@ -319,3 +319,25 @@ def test_product_refuses_cpu_tensors():
         if mod.endswith(".py"):
             src += open(os.path.join(ROOT, "applecider_amd", "models", mod)).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_split_and_tile_planners():
+    """Host-side launch planning (pure Python): split-K factors and the wide-tile choice."""
+    from applecider_amd import hipops as H
+    # long reductions: >= 64 K tiles per workgroup, at most ~4 workgroups per CU
+    assert H._split_for(128, 16064, 524288) == 8
+    # skinny outputs: about one workgroup per CU, >= 8 K tiles each
+    for m, n, k in ((512, 128, 66048), (384, 1536, 4608), (96, 384, 115200), (128, 128, 66048)):
+        s = H._split_for(m, n, k)
+        tiles = -(-m // 128) * -(-n // 128)
+        assert 1 <= s and tiles * s <= 512 and (k // 64) // s >= 8, (m, n, k, s)
+    assert H._split_for(768, 3072, 512) == 1
+    # wide tile for long, wide weight gradients; whole 256-workgroup rounds
+    tile, split = H._tn_plan(128, 16064, 524288)
+    assert tile == 4 and (63 * split) % 256 in range(200, 256)
+    assert H._tn_plan(128, 384, 524288)[0] == 0           # narrow output: 128 x 128 tiles
+    assert H._tn_plan(1024, 6656, 8192)[0] == 0           # short reduction
+    for m, n, k in ((256, 7808, 131072), (512, 7936, 32768), (512, 2816, 32768)):
+        tile, split = H._tn_plan(m, n, k)
+        assert tile == 4 and (k // 64) // split >= 64
+        assert (-(-m // 128) * -(-n // 256) * split) <= 1024
