@@ -53,7 +53,7 @@ class ConvWinDesc(C.Structure):
                 ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("w", C.c_void_p), ("w_row_stride", C.c_int64), ("w_tap_stride", C.c_int64),
                 ("flip", C.c_int32), ("N", C.c_int32), ("c", C.c_void_p), ("ldc", C.c_int64),
-                ("bias", C.c_void_p), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+                ("bias", C.c_void_p), ("accumulate", C.c_int32), ("variant", C.c_int32)]
 
 
 class AdamSeg(C.Structure):

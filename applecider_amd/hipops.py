@@ -297,6 +297,7 @@ def _big(M, N, K) -> bool:
 
 
 _CONVWIN = True
+_CONVWIN_VARIANT = 0   # 1: keep N <= 64 products on the 4-wave window kernel (A/B tests)
 
 
 def enable_conv_window(on: bool):
@@ -317,6 +318,7 @@ def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw
     d.w, d.w_row_stride, d.w_tap_stride = _p(w16), w_row_stride, w_tap_stride
     d.flip, d.N, d.c, d.ldc = int(flip), N, c_ptr, ldc
     d.bias, d.accumulate = _p(bias), int(accumulate)
+    d.variant = _CONVWIN_VARIANT
     rc = _lib_().ac_conv1d_window_bf16(C.byref(d), _stream())
     if rc == _lib.AC_EINVAL:
         return False

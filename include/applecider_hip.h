@@ -162,7 +162,7 @@ typedef struct ac_convwin_desc {
     int64_t ldc;
     const float *bias;
     int32_t accumulate; /* 0 store, 1 out += */
-    int32_t _pad;
+    int32_t variant;    /* 0 auto; 1: never use the 8-wave two-group kernel for N <= 64 (A/B tests) */
 } ac_convwin_desc;
 int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
 

@@ -77,9 +77,11 @@ def win(B, L, C, N, k, flip):
         ms = timeit(f, 3)
         print(f"{'window' if on else 'generic'} B{B} L{L} C{C} N{N} k{k}: {ms:.3f} ms  {2*B*L*N*k*C/ms/1e9:.1f} TF")
 
+for variant in (1, 0):
+    H._CONVWIN_VARIANT = variant
+    print("window variant", variant, "(1 = 4 waves, 0 = auto: two K-parity groups for N <= 64)")
+    win(512, 1024, 128, 64, 251, True)    # stage-2 dX, k = 251
+    win(512, 1024, 128, 64, 31, True)
+    win(512, 1024, 128, 64, 3, True)
+H._CONVWIN_VARIANT = 0
 win(512, 1024, 64, 128, 251, False)   # stage-2 fwd
-win(512, 1024, 128, 64, 251, False)   # stage-2 dX shape (A contiguous here)
-win(512, 256, 128, 256, 61, False)    # stage-3 fwd
-win(512, 256, 256, 128, 61, False)    # stage-3 dX shape
-win(512, 1024, 64, 128, 31, False)
-win(512, 1024, 64, 128, 3, False)
