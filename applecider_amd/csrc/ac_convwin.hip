@@ -224,24 +224,29 @@ int launch(ConvWinParams &p, hipStream_t stream) {
 // (group g multiplies tiles 2p + g), each with its own accumulators; the groups are summed through
 // LDS at the end.  Weight stages hold a pair of tiles (2 x 8 KB), two stages: 32 KB beside the window.
 // ---------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams p) {
-    constexpr int NT = 512, BM = 256;
+template <int WM, int WN, int C>
+__global__ __launch_bounds__(2 * WM * WN * 64, 1) void conv1d_window_ks2_kernel(ConvWinParams p) {
+    constexpr int GW = WM * WN, NT = 2 * GW * 64, BM = WM * 64, BN = WN * 64;
+    constexpr int TILE = BN * 64;          // one 64-deep weight tile (elements)
+    constexpr int BCH = 8 / WM;            // weight chunks per thread per tile pair
+    constexpr int HALF = NT / 2, RPP = HALF / 8;   // threads per tile, rows per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *win = reinterpret_cast<unsigned short *>(smem);
     const ac_convwin_desc &d = p.d;
     const int W = BM + d.k - 1;
-    unsigned short *bst = win + W * C;  // 2 stages x 2 tiles x (64 x 64)
+    unsigned short *bst = win + W * C;  // 2 stages x 2 tiles x (BN x 64)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave & 3, grp = wave >> 2;
+    const int grp = wave / GW, wv = wave % GW;
+    const int wm = wv / WN, wn = wv % WN;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
     const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int tl = wg % p.tiles_l;
-    const int b = wg / p.tiles_l;
+    const int tn = wg % p.tiles_n;
+    const int tl = (wg / p.tiles_n) % p.tiles_l;
+    const int b = wg / (p.tiles_n * p.tiles_l);
     const int l0 = tl * BM;
     {
         const unsigned short *a = (const unsigned short *)d.a + (int64_t)b * d.a_batch_stride +
@@ -253,36 +258,36 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
             *(u32x4 *)(win + win_off<C>(r, cc)) = v;
         }
     }
-    // weight pair loader: thread -> tile (t >> 8), rows ((t & 255) >> 3) + 32 i, chunk t & 7
+    // weight pair loader: thread -> tile (t / HALF), rows ((t % HALF) >> 3) + RPP i, chunk t & 7
     const unsigned short *wptr = (const unsigned short *)d.w;
-    const int ltile = t >> 8, tt = t & 255;
-    int64_t wbase[2];
+    const int ltile = t / HALF, tt = t % HALF;
+    int64_t wbase[BCH];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int n = (tt >> 3) + 32 * i;
+    for (int i = 0; i < BCH; ++i) {
+        int n = tn * BN + (tt >> 3) + RPP * i;
         n = n < d.N ? n : d.N - 1;
         wbase[i] = (int64_t)n * d.w_row_stride + 8 * (tt & 7);
     }
     const int ctiles = C / 64;
     const int nkt = d.k * ctiles;
     const int npairs = (nkt + 1) / 2;
-    auto wload = [&](int pair, u32x4 (&v)[2], unsigned &mask) {
+    auto wload = [&](int pair, u32x4 (&v)[BCH], unsigned &mask) {
         int kt = 2 * pair + ltile;
         mask = (pair < npairs && kt < nkt) ? 0xFFFFFFFFu : 0u;
         kt = kt < nkt ? kt : nkt - 1;
         const int tap = kt / ctiles, c0 = (kt % ctiles) * 64;
         const int64_t ko = (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + c0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) v[i] = ac_gload<u32x4>(wptr + wbase[i] + ko);
+        for (int i = 0; i < BCH; ++i) v[i] = ac_gload<u32x4>(wptr + wbase[i] + ko);
     };
-    auto wstore = [&](unsigned short *stage, const u32x4 (&v)[2], unsigned mask) {
+    auto wstore = [&](unsigned short *stage, const u32x4 (&v)[BCH], unsigned mask) {
         const int c = tt & 7;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (tt >> 3) + 32 * i;
+        for (int i = 0; i < BCH; ++i) {
+            const int r = (tt >> 3) + RPP * i;
             u32x4 w = v[i];
             w[0] &= mask; w[1] &= mask; w[2] &= mask; w[3] &= mask;
-            *(u32x4 *)(stage + ltile * 4096 + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = w;
+            *(u32x4 *)(stage + ltile * TILE + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = w;
         }
     };
     f32x16 acc[2][2];
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
     auto compute = [&](int pair, const unsigned short *stage) {
         int kt = 2 * pair + grp;
         kt = kt < nkt ? kt : nkt - 1;   // past-the-end tile: finite A rows x zero weights
-        const unsigned short *bt = stage + grp * 4096;
+        const unsigned short *bt = stage + grp * TILE;
         const int tap = kt / ctiles, cc0 = (kt % ctiles) * 8;
         const int r0 = wm * 64 + li + tap, r1 = r0 + 32;
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
             const int cc = cc0 + 2 * s + lh;
             const bf16x8 a0 = *(const bf16x8 *)(win + win_off<C>(r0, cc));
             const bf16x8 a1 = *(const bf16x8 *)(win + win_off<C>(r1, cc));
-            const int n0 = li, n1 = n0 + 32;
+            const int n0 = wn * 64 + li, n1 = n0 + 32;
             const int chunk = 2 * s + lh;
             const bf16x8 b0 = *(const bf16x8 *)(bt + n0 * 64 + ((chunk ^ ((n0 >> 1) & 7)) << 3));
             const bf16x8 b1 = *(const bf16x8 *)(bt + n1 * 64 + ((chunk ^ ((n1 >> 1) & 7)) << 3));
@@ -313,8 +318,8 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
     };
-    unsigned short *S0 = bst, *S1 = bst + 2 * 4096;
-    u32x4 rb0[2], rb1[2];
+    unsigned short *S0 = bst, *S1 = bst + 2 * TILE;
+    u32x4 rb0[BCH], rb1[BCH];
     unsigned m0, m1;
     wload(0, rb0, m0);
     wstore(S0, rb0, m0);
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
         __syncthreads();
     }
     // ---- sum the two groups through the (idle) window, then group 0 writes the tile
-    float *xch = smem + wm * 4096;
+    float *xch = smem + wv * 4096;
     if (grp == 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -355,9 +360,9 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
     if (grp == 1) return;
     float *cb = d.c + ((int64_t)b * d.L + l0) * d.ldc;
     if (p.vec_epi) {
-        float *wbuf = smem + wm * 2048;
+        float *wbuf = smem + wv * 2048;
         const int rsub = lane >> 4, c4 = 4 * (lane & 15);
-        const int n = c4;
+        const int n = tn * BN + wn * 64 + c4;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
         if (d.bias && n < d.N) bias4 = *(const f32x4 *)(d.bias + n);
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
         }
         return;
     }
-    const int nn0 = li, nn1 = nn0 + 32;
+    const int nn0 = tn * BN + wn * 64 + li, nn1 = nn0 + 32;
     const float bias0 = (d.bias && nn0 < d.N) ? d.bias[nn0] : 0.f;
     const float bias1 = (d.bias && nn1 < d.N) ? d.bias[nn1] : 0.f;
 #pragma unroll
@@ -398,23 +403,30 @@ __global__ __launch_bounds__(512, 1) void conv1d_window_ks2_kernel(ConvWinParams
     }
 }
 
-template <int C>
+template <int WM, int WN, int C>
+size_t ks2_lds_bytes(int k) {
+    return ((size_t)(WM * 64 + k - 1) * C + 4 * WN * 64 * 64) * sizeof(short);
+}
+
+template <int WM, int WN, int C>
 int launch_ks2(ConvWinParams &p, hipStream_t stream) {
     const ac_convwin_desc &d = p.d;
-    const size_t lds = ((size_t)(256 + d.k - 1) * C + 4 * 4096) * sizeof(short);
-    if (lds > 160 * 1024 || lds < 4 * 4096 * sizeof(float)) return AC_EINVAL;  // (group exchange: 64 KB)
-    p.tiles_l = d.L / 256;
-    p.tiles_n = 1;
+    const size_t lds = ks2_lds_bytes<WM, WN, C>(d.k);
+    // (the group exchange parks WM*WN accumulator tiles of 16 KB in the window)
+    if (lds > 160 * 1024 || (size_t)(WM * 64 + d.k - 1) * C * 2 < (size_t)WM * WN * 16384) return AC_EINVAL;
+    p.tiles_l = d.L / (WM * 64);
+    p.tiles_n = (d.N + WN * 64 - 1) / (WN * 64);
     p.cchunks = C / 8;
     p.vec_epi = (d.N % 4 == 0) && (d.ldc % 4 == 0) && ac_aligned16(d.c) && (!d.bias || ac_aligned16(d.bias));
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_ks2_kernel<C>,
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_ks2_kernel<WM, WN, C>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
-    hipLaunchKernelGGL((conv1d_window_ks2_kernel<C>), dim3(d.B * p.tiles_l), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((conv1d_window_ks2_kernel<WM, WN, C>), dim3(d.B * p.tiles_l * p.tiles_n),
+                       dim3(2 * WM * WN * 64), lds, stream, p);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -428,11 +440,14 @@ int dispatch(ConvWinParams &p, hipStream_t stream) {
     // (0.080 vs 0.105 ms at k = 3); AC_EINVAL sends the caller there
     if (!wide && d.k < 8) return AC_EINVAL;
     // N <= 64, long tap loops: two K-parity groups of 4 waves (variant = 1 forces the 4-wave kernel)
-    if (!wide && d.L % 256 == 0 && d.k >= 8 && win256 + 4 * 4096 * 2 <= 160 * 1024 &&
-        win256 + 4 * 4096 * 2 >= 4 * 4096 * 4 && p.d.variant != 1)
-        return launch_ks2<C>(p, stream);
+    if (!wide && d.L % 256 == 0 && d.k >= 8 && p.d.variant != 1 &&
+        launch_ks2<4, 1, C>(p, stream) == AC_OK)
+        return AC_OK;
     if (d.L % 256 == 0 && win256 + 2 * (wide ? 128 : 64) * 64 * 2 <= 160 * 1024)
         return wide ? launch<4, 2, C>(p, stream) : launch<4, 1, C>(p, stream);
+    // 128-row tiles (the 256-row window does not fit): 4 waves alone on the CU -> two K-parity groups
+    if (wide && d.L % 128 == 0 && d.k >= 8 && p.d.variant != 1 && launch_ks2<2, 2, C>(p, stream) == AC_OK)
+        return AC_OK;
     if (d.L % 128 == 0) return wide ? launch<2, 2, C>(p, stream) : launch<2, 1, C>(p, stream);
     return AC_EINVAL;
 }

@@ -82,6 +82,7 @@ for variant in (1, 0):
     print("window variant", variant, "(1 = 4 waves, 0 = auto: two K-parity groups for N <= 64)")
     win(512, 1024, 128, 64, 251, True)    # stage-2 dX, k = 251
     win(512, 1024, 128, 64, 31, True)
-    win(512, 1024, 128, 64, 3, True)
+    win(512, 256, 256, 128, 61, True)     # stage-3 dX: 128-row tiles (the 256-row window does not fit)
+    win(512, 256, 256, 128, 15, True)
 H._CONVWIN_VARIANT = 0
 win(512, 1024, 64, 128, 251, False)   # stage-2 fwd
