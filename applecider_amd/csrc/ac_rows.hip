@@ -876,7 +876,9 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     }
     if (dx16 || !dx || dy_bf16) return AC_EALIGN;  // bf16 in/out exist on the sub-wave path only
     if (vec4 && !vec && C <= 3072) {
-        int64_t g = rows < 2048 ? rows : 2048;
+        // few workgroups: every one ends with 3*C global atomics onto the same 3*C addresses, and
+        // 2048 adders per address made that flush, not the streaming, the cost (0.47 ms for 100 MB)
+        int64_t g = rows < 512 ? rows : 512;
         hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((int)g), dim3(ROWS_BLOCK), 0, stream, dy,
                            lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, rows,
                            C, act);
