@@ -263,6 +263,17 @@ def test_pools(dev):
     close(yd, y, tol=0, name="maxpool")
     close(xd.grad, x.grad, tol=0, name="maxpool dx")
     x.grad = None
+    # shapes off the 16-byte path (C % 4 != 0, L % 4 != 0: tail rows get a zero gradient) and ties
+    for shape in ((2, 66, 41), (2, 64, 6), (5, 128, 64)):
+        xs = g(dev, *shape, seed=7).round().requires_grad_()        # rounded: many equal maxima
+        ys = F.max_pool1d(xs.permute(0, 2, 1), 4).permute(0, 2, 1)
+        gs = g(dev, *ys.shape, seed=8)
+        ys.backward(gs)
+        xsd = xs.detach().to(dev).requires_grad_()
+        ysd = H.maxpool4(xsd)
+        ysd.backward(gs.to(dev))
+        close(ysd, ys, tol=0, name=f"maxpool {shape}")
+        close(xsd.grad, xs.grad, tol=0, name=f"maxpool dx {shape}")
     y = F.adaptive_max_pool1d(x.permute(0, 2, 1), 1).squeeze(-1)
     go = g(dev, *y.shape, seed=3)
     y.backward(go)
