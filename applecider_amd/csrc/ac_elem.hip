@@ -270,17 +270,15 @@ __global__ void pad_rows_kernel(const float *x, float *y, int B, int L, int C, i
 __global__ void pad_rows_bf16_kernel(const float *x, unsigned short *y, int B, int L, int C,
                                      int pad_lo, int Lp) {
     const int C8 = C >> 3;
-    const int64_t n = (int64_t)B * Lp * C8;
-    GSTRIDE(i, n) {
-        int c8 = (int)(i % C8);
-        int64_t t = i / C8;
-        int lp = (int)(t % Lp);
-        int64_t b = t / Lp;
-        int l = lp - pad_lo;
+    const unsigned n = (unsigned)B * Lp * C8;   // < 2^31 (checked by the launcher): 32-bit div/mod
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned c8 = i % C8, t = i / C8;
+        const unsigned lp = t % Lp, b = t / Lp;
+        const int l = (int)lp - pad_lo;
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
         if (l >= 0 && l < L) {
-            const float *src = x + (b * L + l) * C + 8 * c8;
+            const float *src = x + ((int64_t)b * L + l) * C + 8 * c8;
             const f32x4 a = *(const f32x4 *)src, bb = *(const f32x4 *)(src + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -289,7 +287,7 @@ __global__ void pad_rows_bf16_kernel(const float *x, unsigned short *y, int B, i
                 o[4 + j] = *reinterpret_cast<short *>(&h1);
             }
         }
-        *(s16x8 *)(y + i * 8) = o;
+        *(s16x8 *)(y + (int64_t)i * 8) = o;
     }
 }
 __global__ void pad_rows_bf16_scalar_kernel(const float *x, unsigned short *y, int B, int L, int C,
@@ -507,7 +505,7 @@ extern "C" int ac_pad_rows(const float *x, float *y, int32_t B, int32_t L, int32
 extern "C" int ac_pad_rows_bf16(const float *x, void *y, int32_t B, int32_t L, int32_t C,
                                 int32_t pad_lo, int32_t Lp, ac_stream_t stream) {
     if (!x || !y || B <= 0 || L <= 0 || C <= 0 || pad_lo < 0 || Lp < L + pad_lo) return AC_EINVAL;
-    if (C % 8 == 0 && ac_aligned16(x) && ac_aligned16(y))
+    if (C % 8 == 0 && ac_aligned16(x) && ac_aligned16(y) && (int64_t)B * Lp * (C / 8) < (1ll << 31))
         EW_LAUNCH(pad_rows_bf16_kernel, (int64_t)B * Lp * (C / 8), x, (unsigned short *)y, B, L, C,
                   pad_lo, Lp);
     EW_LAUNCH(pad_rows_bf16_scalar_kernel, (int64_t)B * Lp * C, x, (unsigned short *)y, B, L, C, pad_lo,
