@@ -357,6 +357,11 @@ def _tn_plan(m_out: int, n_out: int, k_red: int):
                 best = (waste, split)
         if best is not None:
             return 4, best[1]
+    if m_out >= 1024 and n_out >= 1024 and nkt >= 64:
+        # short reductions over a large output (last SpectraNet stage): 256 x 128 tiles, about one
+        # workgroup per CU (207 vs 279 us at 1024 x 6656 x 8192, tools/bench_tn_late.py)
+        tiles = -(-m_out // 256) * -(-n_out // 128)
+        return 3, max(1, min(256 // tiles, nkt // 16))
     return 0, _split_for(m_out, n_out, k_red)
 
 

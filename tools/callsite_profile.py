@@ -16,6 +16,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 H.set_math("bf16")
 torch.manual_seed(0)
 net = AppleCider(dict(bench.FUSION_CFG)).to(dev).train()
+net.branch_streams = False    # one stream: per-launch times without overlap
 net.optimizer.prepare()
 b = make_batch(B, seed=2)
 batch = tuple(torch.from_numpy(b[k]).to(dev) for k in
