@@ -336,7 +336,8 @@ def test_split_and_tile_planners():
     tile, split = H._tn_plan(128, 16064, 524288)
     assert tile == 4 and (63 * split) % 256 in range(200, 256)
     assert H._tn_plan(128, 384, 524288)[0] == 0           # narrow output: 128 x 128 tiles
-    assert H._tn_plan(1024, 6656, 8192)[0] == 0           # short reduction
+    assert H._tn_plan(1024, 6656, 8192) == (3, 1)         # short reduction, large output: 256 x 128 tiles
+    assert H._tn_plan(512, 768, 32768)[0] == 0            # narrow output of a middle stage
     for m, n, k in ((256, 7808, 131072), (512, 7936, 32768), (512, 2816, 32768)):
         tile, split = H._tn_plan(m, n, k)
         assert tile == 4 and (k // 64) // split >= 64
