@@ -174,7 +174,8 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n
 enum : unsigned {
     E_BIAS = 1u, E_PRE = 2u, E_GELU = 4u, E_RELU = 8u, E_DGELU = 16u, E_MASK16 = 32u, E_CSCALE = 64u,
     E_DROP = 128u, E_RES = 256u, E_C16 = 512u, E_C32 = 1024u, E_ACC = 2048u,
-    E_FAST = 4096u  // bf16 math modes: rational erf inside GELU / GELU'
+    E_FAST = 4096u,  // bf16 math modes: rational erf inside GELU / GELU'
+    E_GOFF = 8192u   // C columns through the offset table (conv outputs scattered into the cat buffer)
 };
 #define AC_EPI_VARIANTS(X)                                                                      \
     X(0, E_C32) X(1, E_C32 | E_BIAS) X(2, E_C16 | E_BIAS | E_GELU | E_PRE)                       \
@@ -183,12 +184,13 @@ enum : unsigned {
     X(8, E_C32 | E_ACC) X(9, E_C32 | E_BIAS | E_RES) X(10, E_C16 | E_BIAS | E_RELU)              \
     X(11, E_C16 | E_BIAS | E_GELU) X(12, E_C32 | E_BIAS | E_CSCALE | E_RES) X(13, E_C32 | E_BIAS | E_GELU) \
     X(14, E_C16 | E_BIAS | E_GELU | E_PRE | E_FAST) X(15, E_C16 | E_DGELU | E_FAST)               \
-    X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)
+    X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)     \
+    X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF)
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
 __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int n, f32x4 v,
-                                               const f32x4 &bias4, const f32x4 &cs4) {
+                                               const f32x4 &bias4, const f32x4 &cs4, int64_t ccol) {
     v *= d.alpha;
     if constexpr (F & E_BIAS) v += bias4;  // per-column vectors are loaded once per tile
     if constexpr (F & E_PRE) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
@@ -226,7 +228,8 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int
         *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + n) = h;
     }
     if constexpr (F & E_C32) {
-        f32x4 *c = (f32x4 *)((float *)d.c.ptr + (int64_t)m * d.c.rows.s3 + n);  // plain row-major C
+        // plain row-major C; with E_GOFF the column offset comes from the table (looked up once per tile)
+        f32x4 *c = (f32x4 *)((float *)d.c.ptr + (int64_t)m * d.c.rows.s3 + ((F & E_GOFF) ? ccol : (int64_t)n));
         if constexpr (F & E_ACC) *c += v; else *c = v;
     }
 }
@@ -237,7 +240,7 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
     const int li = lane & 31, lh = lane >> 5;
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = col_base + c4;
-    const int64_t coff = (VAR == EPI_GENERIC && n < d.N) ? inner_off(d.c.goff, n) : 0;
+    const int64_t coff = (d.c.goff != nullptr && n < d.N) ? inner_off(d.c.goff, n) : (int64_t)n;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cs4 = {1.f, 1.f, 1.f, 1.f};
     if (VAR != EPI_GENERIC && n < d.N) {
         if (d.bias) bias4 = *(const f32x4 *)(d.bias + n);
@@ -261,7 +264,7 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
                 if constexpr (VAR == EPI_GENERIC) {
                     epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
                 } else {
-#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v, bias4, cs4);
+#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v, bias4, cs4, coff);
                     AC_EPI_VARIANTS(AC_EPI_CALL)
 #undef AC_EPI_CALL
                 }
@@ -1070,8 +1073,8 @@ bool rowmap_aligned(const ac_rowmap &r) {
 }
 
 int epilogue_variant(const ac_gemm_desc &d, int accumulate) {
-    if (d.c.rows.r1 != 0 || d.c.goff || accumulate == 2) return EPI_GENERIC;
-    unsigned f = 0;
+    if (d.c.rows.r1 != 0 || accumulate == 2) return EPI_GENERIC;
+    unsigned f = d.c.goff ? E_GOFF : 0;
     if (d.bias) f |= E_BIAS;
     if (d.pre_out) f |= E_PRE;
     if (d.act == AC_ACT_GELU) f |= E_GELU;
