@@ -53,7 +53,8 @@ class ConvWinDesc(C.Structure):
                 ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
                 ("w", C.c_void_p), ("w_row_stride", C.c_int64), ("w_tap_stride", C.c_int64),
                 ("flip", C.c_int32), ("N", C.c_int32), ("c", C.c_void_p), ("ldc", C.c_int64),
-                ("bias", C.c_void_p), ("accumulate", C.c_int32), ("variant", C.c_int32)]
+                ("bias", C.c_void_p), ("accumulate", C.c_int32), ("variant", C.c_int32),
+                ("c16", C.c_void_p), ("ldc16", C.c_int64)]
 
 
 class AdamSeg(C.Structure):
@@ -73,9 +74,9 @@ SIGNATURES = {
     "ac_cast_bf16": [_P, _P, _I64, _P],
     "ac_transpose_cast_bf16": [_P, _I64, _P, _I64, _I64, _I32, _P],
     "ac_transpose_cast_segments": [_P, _P, _P, _I32, _I32, _P],
-    "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _P],
+    "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _I32, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
-                         _P, _I64, _I32, _I32, _I32, _I32, _P],
+                         _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_mpt_mask": [_P, _P, _P, _I32, _I32, C.c_double, C.c_uint64, _P],
     "ac_mpt_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _F, _F, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],

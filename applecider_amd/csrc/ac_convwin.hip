@@ -20,6 +20,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+__device__ __forceinline__ unsigned short win_bf16(float x) {
+    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+}
+
 struct ConvWinParams {
     ac_convwin_desc d;
     int tiles_l, tiles_n, cchunks;  // cchunks = C / 8 (16-byte chunks per window row)
@@ -170,9 +174,17 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
                 const int r = it * 4 + rsub;
                 f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
                 if (n < d.N) {
-                    f32x4 *dst = (f32x4 *)(cb + (int64_t)(wm * 64 + sa * 32 + r) * d.ldc + n);
-                    if (d.accumulate) v += *dst;
-                    *dst = v;
+                    const int64_t row = wm * 64 + sa * 32 + r;
+                    if (d.c16) {
+                        ushort4 h;
+                        h.x = win_bf16(v[0]); h.y = win_bf16(v[1]); h.z = win_bf16(v[2]); h.w = win_bf16(v[3]);
+                        *(ushort4 *)((unsigned short *)d.c16 + ((int64_t)b * d.L + l0 + row) * d.ldc16 + n) = h;
+                    }
+                    if (d.c) {
+                        f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
+                        if (d.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -186,10 +198,17 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = wm * 64 + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            float *row = cb + (int64_t)m * d.ldc;
             const float v0 = acc[sa][0][e] + bias0, v1 = acc[sa][1][e] + bias1;
-            if (nn0 < d.N) row[nn0] = d.accumulate ? row[nn0] + v0 : v0;
-            if (nn1 < d.N) row[nn1] = d.accumulate ? row[nn1] + v1 : v1;
+            if (d.c16) {
+                unsigned short *r16 = (unsigned short *)d.c16 + ((int64_t)b * d.L + l0 + m) * d.ldc16;
+                if (nn0 < d.N) r16[nn0] = win_bf16(v0);
+                if (nn1 < d.N) r16[nn1] = win_bf16(v1);
+            }
+            if (d.c) {
+                float *row = cb + (int64_t)m * d.ldc;
+                if (nn0 < d.N) row[nn0] = d.accumulate ? row[nn0] + v0 : v0;
+                if (nn1 < d.N) row[nn1] = d.accumulate ? row[nn1] + v1 : v1;
+            }
         }
     }
 }
@@ -203,7 +222,9 @@ int launch(ConvWinParams &p, hipStream_t stream) {
     p.tiles_l = d.L / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.cchunks = C / 8;
-    p.vec_epi = (d.N % 4 == 0) && (d.ldc % 4 == 0) && ac_aligned16(d.c) && (!d.bias || ac_aligned16(d.bias));
+    p.vec_epi = (d.N % 4 == 0) && (!d.c || ((d.ldc % 4 == 0) && ac_aligned16(d.c))) &&
+                (!d.bias || ac_aligned16(d.bias)) &&
+                (!d.c16 || (d.ldc16 % 4 == 0 && ((uintptr_t)d.c16 & 7u) == 0));
     static size_t configured = 0;  // grow-only attribute (benign race: same value from any thread)
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_kernel<WM, WN, C>,
@@ -379,9 +400,17 @@ __global__ __launch_bounds__(2 * WM * WN * 64, 1) void conv1d_window_ks2_kernel(
                 const int r = it * 4 + rsub;
                 f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
                 if (n < d.N) {
-                    f32x4 *dst = (f32x4 *)(cb + (int64_t)(wm * 64 + sa * 32 + r) * d.ldc + n);
-                    if (d.accumulate) v += *dst;
-                    *dst = v;
+                    const int64_t row = wm * 64 + sa * 32 + r;
+                    if (d.c16) {
+                        ushort4 h;
+                        h.x = win_bf16(v[0]); h.y = win_bf16(v[1]); h.z = win_bf16(v[2]); h.w = win_bf16(v[3]);
+                        *(ushort4 *)((unsigned short *)d.c16 + ((int64_t)b * d.L + l0 + row) * d.ldc16 + n) = h;
+                    }
+                    if (d.c) {
+                        f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
+                        if (d.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -395,10 +424,17 @@ __global__ __launch_bounds__(2 * WM * WN * 64, 1) void conv1d_window_ks2_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = wm * 64 + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            float *row = cb + (int64_t)m * d.ldc;
             const float v0 = acc[sa][0][e] + bias0, v1 = acc[sa][1][e] + bias1;
-            if (nn0 < d.N) row[nn0] = d.accumulate ? row[nn0] + v0 : v0;
-            if (nn1 < d.N) row[nn1] = d.accumulate ? row[nn1] + v1 : v1;
+            if (d.c16) {
+                unsigned short *r16 = (unsigned short *)d.c16 + ((int64_t)b * d.L + l0 + m) * d.ldc16;
+                if (nn0 < d.N) r16[nn0] = win_bf16(v0);
+                if (nn1 < d.N) r16[nn1] = win_bf16(v1);
+            }
+            if (d.c) {
+                float *row = cb + (int64_t)m * d.ldc;
+                if (nn0 < d.N) row[nn0] = d.accumulate ? row[nn0] + v0 : v0;
+                if (nn1 < d.N) row[nn1] = d.accumulate ? row[nn1] + v1 : v1;
+            }
         }
     }
 }
@@ -417,7 +453,9 @@ int launch_ks2(ConvWinParams &p, hipStream_t stream) {
     p.tiles_l = d.L / (WM * 64);
     p.tiles_n = (d.N + WN * 64 - 1) / (WN * 64);
     p.cchunks = C / 8;
-    p.vec_epi = (d.N % 4 == 0) && (d.ldc % 4 == 0) && ac_aligned16(d.c) && (!d.bias || ac_aligned16(d.bias));
+    p.vec_epi = (d.N % 4 == 0) && (!d.c || ((d.ldc % 4 == 0) && ac_aligned16(d.c))) &&
+                (!d.bias || ac_aligned16(d.bias)) &&
+                (!d.c16 || (d.ldc16 % 4 == 0 && ((uintptr_t)d.c16 & 7u) == 0));
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_ks2_kernel<WM, WN, C>,
@@ -459,7 +497,8 @@ extern "C" int ac_conv1d_window_bf16(const ac_convwin_desc *dp, ac_stream_t stre
     ConvWinParams p;
     p.d = *dp;
     const ac_convwin_desc &d = p.d;
-    if (!d.a || !d.w || !d.c || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.N <= 0) return AC_EINVAL;
+    if (!d.a || !d.w || (!d.c && !d.c16) || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.N <= 0) return AC_EINVAL;
+    if (!d.c && d.accumulate) return AC_EINVAL;
     if (!ac_aligned16(d.a) || !ac_aligned16(d.w)) return AC_EALIGN;
     if ((d.a_row_stride % 8) || (d.a_batch_stride % 8) || (d.a_col_off % 8) || (d.w_row_stride % 8) ||
         (d.w_tap_stride % 8))

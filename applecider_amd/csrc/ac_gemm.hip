@@ -44,6 +44,10 @@ __device__ __forceinline__ float epi_bf16_to_f32(unsigned short h) {
     return __builtin_bit_cast(float, (unsigned)h << 16);
 }
 
+__device__ __forceinline__ int64_t inner_off(const int32_t *goff, int i) {
+    return goff ? (int64_t)goff[i >> 5] + (i & 31) : (int64_t)i;
+}
+
 __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int n, float acc,
                                                int64_t caddr) {
     float v = acc * d.alpha;
@@ -57,7 +61,7 @@ __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int
         v = ac_rand01(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n) >= d.drop_p
                 ? v * (1.0f / (1.0f - d.drop_p)) : 0.f;
     if (d.residual) v += d.residual[(int64_t)m * d.ld_res + n];
-    if (d.c16) ((unsigned short *)d.c16)[(int64_t)m * d.ld_c16 + n] = epi_bf16(v);
+    if (d.c16) ((unsigned short *)d.c16)[(int64_t)m * d.ld_c16 + inner_off(d.c.goff, n)] = epi_bf16(v);
     if (!d.c.ptr) return;
     float *c = (float *)d.c.ptr + caddr;
     if (d.accumulate == 2)
@@ -66,10 +70,6 @@ __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int
         *c += v;
     else
         *c = v;
-}
-
-__device__ __forceinline__ int64_t inner_off(const int32_t *goff, int i) {
-    return goff ? (int64_t)goff[i >> 5] + (i & 31) : (int64_t)i;
 }
 
 template <int I, int N, typename F>
@@ -156,7 +156,7 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n
     if (d.c16) {
         ushort4 h;
         h.x = epi_bf16(v[0]); h.y = epi_bf16(v[1]); h.z = epi_bf16(v[2]); h.w = epi_bf16(v[3]);
-        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + n) = h;
+        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + inner_off(d.c.goff, n)) = h;
     }
     if (!d.c.ptr) return;
     f32x4 *c = (f32x4 *)((float *)d.c.ptr + caddr);
@@ -185,7 +185,7 @@ enum : unsigned {
     X(11, E_C16 | E_BIAS | E_GELU) X(12, E_C32 | E_BIAS | E_CSCALE | E_RES) X(13, E_C32 | E_BIAS | E_GELU) \
     X(14, E_C16 | E_BIAS | E_GELU | E_PRE | E_FAST) X(15, E_C16 | E_DGELU | E_FAST)               \
     X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)     \
-    X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF)
+    X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF) X(21, E_C16 | E_BIAS | E_GOFF)
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
@@ -225,7 +225,7 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int
     if constexpr (F & E_C16) {
         ushort4 h;
         h.x = epi_bf16(v[0]); h.y = epi_bf16(v[1]); h.z = epi_bf16(v[2]); h.w = epi_bf16(v[3]);
-        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + n) = h;
+        *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + ((F & E_GOFF) ? ccol : (int64_t)n)) = h;
     }
     if constexpr (F & E_C32) {
         // plain row-major C; with E_GOFF the column offset comes from the table (looked up once per tile)

@@ -287,7 +287,21 @@ __device__ __forceinline__ unsigned short ln_bf16(float x) {
     return (unsigned short)(u >> 16);
 }
 
-template <int G, int J>
+// 4 consecutive values of a row that is fp32 or (is16) bf16 in memory; ld in elements
+__device__ __forceinline__ f32x4 ln_load4(const float *base, int64_t elem, int is16) {
+    if (is16) {
+        const ushort4 h = *(const ushort4 *)((const unsigned short *)base + elem);
+        f32x4 v;
+        v[0] = __builtin_bit_cast(float, (unsigned)h.x << 16);
+        v[1] = __builtin_bit_cast(float, (unsigned)h.y << 16);
+        v[2] = __builtin_bit_cast(float, (unsigned)h.z << 16);
+        v[3] = __builtin_bit_cast(float, (unsigned)h.w << 16);
+        return v;
+    }
+    return *(const f32x4 *)(base + elem);
+}
+
+template <int G, int J, bool X16>
 __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_sub_kernel(
     const float *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ y, int64_t ldy,
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_sub_kernel(
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            v[j] = *(const f32x4 *)(x + r * ldx + 4 * (sub + G * j));
+            v[j] = ln_load4(x, r * ldx + 4 * (sub + G * j), X16);
             s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         }
         const float mu = ac_group_sum<G>(s) * invC;
@@ -345,14 +359,14 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_sub_kernel(
     }
 }
 
-template <int G, int J>
+template <int G, int J, bool X16, bool DY16>
 __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
     const float *__restrict__ dy, int64_t lddy, const float *__restrict__ x, int64_t ldx,
     const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
     int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ dxsum, int64_t rows, int act, unsigned short *__restrict__ dx16,
-    int64_t lddx16, int seg_len, int seg_pitch, int seg_off, int dy_bf16) {
+    int64_t lddx16, int seg_len, int seg_pitch, int seg_off) {
     constexpr int RPW = 64 / G, C = 4 * G * J;
     __shared__ __attribute__((aligned(16))) float sacc[3 * C];
     const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -373,16 +387,8 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            xh[j] = *(const f32x4 *)(x + r * ldx + 4 * (sub + G * j));
-            if (dy_bf16) {  // the upstream product handed its input gradient over in bf16
-                const ushort4 h = *(const ushort4 *)((const unsigned short *)dy + r * lddy + 4 * (sub + G * j));
-                d[j][0] = __builtin_bit_cast(float, (unsigned)h.x << 16);
-                d[j][1] = __builtin_bit_cast(float, (unsigned)h.y << 16);
-                d[j][2] = __builtin_bit_cast(float, (unsigned)h.z << 16);
-                d[j][3] = __builtin_bit_cast(float, (unsigned)h.w << 16);
-            } else {
-                d[j] = *(const f32x4 *)(dy + r * lddy + 4 * (sub + G * j));
-            }
+            xh[j] = ln_load4(x, r * ldx + 4 * (sub + G * j), X16);
+            d[j] = ln_load4(dy, r * lddy + 4 * (sub + G * j), DY16);
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -793,27 +799,34 @@ inline int grid_for_rows(int64_t rows, int rows_per_block, int cap) {
 extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
                                 const float *beta, float *y, int64_t ldy, float *mean,
                                 float *rstd, int64_t rows, int32_t C, float eps, int32_t act,
-                                void *y16, int64_t ldy16, ac_stream_t stream) {
+                                void *y16, int64_t ldy16, int32_t x_bf16, ac_stream_t stream) {
     if (!x || !gamma || !beta || (!y && !y16) || rows < 0 || C <= 0) return AC_EINVAL;
     if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
     if (rows == 0) return AC_OK;
-    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ac_aligned16(x) &&
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+                     (x_bf16 ? (((uintptr_t)x & 7u) == 0) : ac_aligned16(x)) &&
                      ac_aligned16(y) && ac_aligned16(gamma) && ac_aligned16(beta);
     int G = 0, J = 0;
     const bool sub = vec && ln_sub_shape(C, &G, &J) && (!y16 || (((uintptr_t)y16 & 7u) == 0 && ldy16 % 4 == 0));
     if (sub) {
         const int g2 = grid_for_rows(rows, 4 * (64 / G) * 2, 2048);
 #define LN_FWD_SUB(GG, JJ)                                                                        \
-    if (G == GG && J == JJ)                                                                       \
-        hipLaunchKernelGGL((layernorm_fwd_sub_kernel<GG, JJ>), dim3(g2), dim3(ROWS_BLOCK), 0,    \
-                           (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,                      \
-                           (unsigned short *)y16, ldy16, mean, rstd, rows, eps, act);
+    if (G == GG && J == JJ) {                                                                     \
+        if (x_bf16)                                                                               \
+            hipLaunchKernelGGL((layernorm_fwd_sub_kernel<GG, JJ, true>), dim3(g2), dim3(ROWS_BLOCK), 0, \
+                               (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,                  \
+                               (unsigned short *)y16, ldy16, mean, rstd, rows, eps, act);         \
+        else                                                                                      \
+            hipLaunchKernelGGL((layernorm_fwd_sub_kernel<GG, JJ, false>), dim3(g2), dim3(ROWS_BLOCK), 0, \
+                               (hipStream_t)stream, x, ldx, gamma, beta, y, ldy,                  \
+                               (unsigned short *)y16, ldy16, mean, rstd, rows, eps, act);         \
+    }
         LN_SUB_CASES(LN_FWD_SUB)
 #undef LN_FWD_SUB
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
-    if (y16 || !y) return AC_EALIGN;  // the bf16 side output exists on the sub-wave path only
+    if (y16 || !y || x_bf16) return AC_EALIGN;  // bf16 in/out exist on the sub-wave path only
     const int grid = grid_for_rows(rows, ROWS_BLOCK / 64, 256 * 16);
     if (vec && C <= 1536) {
         const int g2 = grid_for_rows(rows, 16, 2048);
@@ -843,7 +856,7 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
                                 const float *beta, float *dx, int64_t lddx, float *dgamma,
                                 float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
                                 void *dx16, int64_t lddx16, int32_t seg_len, int32_t seg_pitch,
-                                int32_t seg_off, int32_t dy_bf16, ac_stream_t stream_) {
+                                int32_t seg_off, int32_t dy_bf16, int32_t x_bf16, ac_stream_t stream_) {
     if (!dy || !x || !mean || !rstd || !gamma || (!dx && !dx16) || rows < 0 || C <= 0)
         return AC_EINVAL;
     if (seg_len < 0 || (seg_len > 0 && (rows % seg_len || seg_pitch < seg_len + seg_off || seg_off < 0)))
@@ -854,7 +867,8 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     if (rows == 0) return AC_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = (C % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) &&
-                      (dy_bf16 ? (((uintptr_t)dy & 7u) == 0) : ac_aligned16(dy)) && ac_aligned16(x) &&
+                      (dy_bf16 ? (((uintptr_t)dy & 7u) == 0) : ac_aligned16(dy)) &&
+                      (x_bf16 ? (((uintptr_t)x & 7u) == 0) : ac_aligned16(x)) &&
                       ac_aligned16(dx) &&
                       ac_aligned16(gamma) && (!beta || ac_aligned16(beta));
     const bool vec = vec4 && C <= 1536;
@@ -863,18 +877,26 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
     const bool dx16_ok = !dx16 || (((uintptr_t)dx16 & 7u) == 0 && lddx16 % 4 == 0);
     if (vec4 && dx16_ok && ln_sub_shape(C, &G, &J)) {
         const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 2048);
+#define LN_BWD_ARGS                                                                              \
+    dim3(grid), dim3(ROWS_BLOCK), 0, stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx,    \
+        dgamma, dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len, seg_pitch, seg_off
 #define LN_BWD_SUB(GG, JJ)                                                                       \
-    if (G == GG && J == JJ)                                                                      \
-        hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ>), dim3(grid), dim3(ROWS_BLOCK), 0, \
-                           stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma,  \
-                           dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len,     \
-                           seg_pitch, seg_off, dy_bf16);
+    if (G == GG && J == JJ) {                                                                    \
+        if (x_bf16 && dy_bf16)                                                                   \
+            hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ, true, true>), LN_BWD_ARGS);     \
+        else if (x_bf16)                                                                         \
+            hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ, true, false>), LN_BWD_ARGS);    \
+        else if (dy_bf16)                                                                        \
+            hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ, false, true>), LN_BWD_ARGS);    \
+        else                                                                                     \
+            hipLaunchKernelGGL((layernorm_bwd_sub_kernel<GG, JJ, false, false>), LN_BWD_ARGS);   \
+    }
         LN_SUB_CASES(LN_BWD_SUB)
 #undef LN_BWD_SUB
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
-    if (dx16 || !dx || dy_bf16) return AC_EALIGN;  // bf16 in/out exist on the sub-wave path only
+    if (dx16 || !dx || dy_bf16 || x_bf16) return AC_EALIGN;  // bf16 in/out exist on the sub-wave path only
     if (vec4 && !vec && C <= 3072) {
         // few workgroups: every one ends with 3*C global atomics onto the same 3*C addresses, and
         // 2048 adders per address made that flush, not the streaming, the cost (0.47 ms for 100 MB)

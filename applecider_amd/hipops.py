@@ -297,6 +297,20 @@ def _big(M, N, K) -> bool:
 
 
 _CONVWIN = True
+_CAT16 = True   # bf16 conv-bank output in front of the fused LayerNorm (bf16 math mode); tests switch it
+
+
+class _View16:
+    """Pointer + element offset of a bf16 tensor, for `_p()` (column block of the cat buffer)."""
+
+    def __init__(self, t, elem_off):
+        self.t, self.off = t, elem_off
+
+    def data_ptr(self):
+        return self.t.data_ptr() + 2 * self.off
+
+    def element_size(self):
+        return 2
 _CONVWIN_VARIANT = 0   # 1: keep N <= 64 products on the 4-wave window kernel (A/B tests)
 
 
@@ -306,7 +320,7 @@ def enable_conv_window(on: bool):
 
 
 def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w16, w_row_stride,
-                w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate) -> bool:
+                w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate, c16_ptr=None, ldc16=0) -> bool:
     """LDS-resident-window conv1d (ac_conv1d_window_bf16).  Returns False when the shape is not
     covered (the caller then uses the generic gather-GEMM)."""
     if not _CONVWIN or Cw not in (64, 128, 256) or L % 128:
@@ -319,6 +333,7 @@ def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw
     d.flip, d.N, d.c, d.ldc = int(flip), N, c_ptr, ldc
     d.bias, d.accumulate = _p(bias), int(accumulate)
     d.variant = _CONVWIN_VARIANT
+    d.c16, d.ldc16 = c16_ptr, ldc16
     rc = _lib_().ac_conv1d_window_bf16(C.byref(d), _stream())
     if rc == _lib.AC_EINVAL:
         return False
@@ -682,7 +697,7 @@ class _LayerNorm(Function):
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         y16 = _side16_alloc(x.shape, Cn, x.device)
         _lib.check(_lib_().ac_layernorm_fwd(_p(x), Cn, _p(gamma), _p(beta), _p(y), Cn, _p(mean),
-                                            _p(rstd), rows, Cn, eps, act, _p(y16), Cn, _stream()),
+                                            _p(rstd), rows, Cn, eps, act, _p(y16), Cn, 0, _stream()),
                    "ac_layernorm_fwd")
         if y16 is not None:
             y._ac16 = y16   # the matrix product that consumes y reads this instead of casting
@@ -704,7 +719,7 @@ class _LayerNorm(Function):
         db = bs if both else torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
                                             _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
-                                            ctx.act, None, 0, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
+                                            ctx.act, None, 0, 0, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
         if both:
             _grad_written(ctx.gp)
             _grad_written(ctx.bp)
@@ -1184,11 +1199,15 @@ class _ConvGroup1d(Function):
                 raise ValueError("ConvGroup1d supports odd kernel sizes ('same' padding k//2)")
         Pmax = max(ksizes) // 2
         dev = x.device
-        ycat = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
         ctx.ksizes, ctx.dims = tuple(ksizes), (B, L, Cin, Cout, Pmax)
         ctx.has_b = [b is not None for b in bs]
         b16 = ctx.b16 = bf16_operands()
         mth = _lib.MATH_BF16_IN if b16 else None
+        # bf16 mode with the fused LayerNorm: the concatenated conv outputs exist in bf16 only — they
+        # are written once by the conv epilogues and read by LayerNorm forward and backward (4.7 GB of
+        # HBM traffic per step at the benchmark shape when kept in fp32)
+        cat16 = ctx.cat16 = bool(b16 and ln_gamma is not None and _ln_sub_shape(Ncat) and _CAT16)
+        ycat = torch.empty(B, L, Ncat, device=dev, dtype=torch.bfloat16 if cat16 else torch.float32)
         if Cin == 1:
             if L % 8:
                 raise ValueError("Cin == 1 path needs L % 8 == 0")
@@ -1211,10 +1230,15 @@ class _ConvGroup1d(Function):
                 # bias[(r,co)] = b[co]; 8*Cout floats of plumbing
                 bexp = bs[j].detach().repeat(8) if bs[j] is not None else None
                 wop = cast16(wexp) if b16 else wexp
-                gemm(AC_GEMM_NT, B * Lq, 8 * Cout, Kp,
-                     mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8),
-                     mat(_p(wop), Kp),
-                     mat(_p(ycat), 8 * Ncat, goff=goff_c), bias=bexp, math=mth)
+                if cat16:
+                    gemm(AC_GEMM_NT, B * Lq, 8 * Cout, Kp,
+                         mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(wop), Kp),
+                         mat(None, 8 * Ncat, goff=goff_c), bias=bexp, c16=ycat, ld_c16=8 * Ncat, math=mth)
+                else:
+                    gemm(AC_GEMM_NT, B * Lq, 8 * Cout, Kp,
+                         mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8),
+                         mat(_p(wop), Kp),
+                         mat(_p(ycat), 8 * Ncat, goff=goff_c), bias=bexp, math=mth)
                 saved_meta.append((base, shift, Kp, goff_c))
             ctx.meta = saved_meta
             ctx.Lp = Lp
@@ -1226,6 +1250,14 @@ class _ConvGroup1d(Function):
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 wop = cast16_w(ws[j]) if b16 else ws[j]
+                if cat16:
+                    if conv_window(xpad, Lp * Cin, Cin, 0, off, B, L, Cin, k, wop, k * Cin, Cin, False,
+                                   Cout, None, Ncat, bs[j], False, c16_ptr=_p(ycat, j * Cout), ldc16=Ncat):
+                        continue
+                    gemm(AC_GEMM_NT, B * L, Cout, k * Cin,
+                         mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin), mat(_p(wop), k * Cin),
+                         mat(None, Ncat), bias=bs[j], c16=_View16(ycat, j * Cout), ld_c16=Ncat, math=mth)
+                    continue
                 if b16 and conv_window(xpad, Lp * Cin, Cin, 0, off, B, L, Cin, k, wop, k * Cin, Cin,
                                        False, Cout, _p(ycat, j * Cout), Ncat, bs[j], False):
                     continue
@@ -1238,7 +1270,7 @@ class _ConvGroup1d(Function):
         ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
         if ctx.fused_ln:
             rows = B * L
-            y = torch.empty_like(ycat)
+            y = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
             mean = torch.empty(rows, device=dev, dtype=torch.float32)
             rstd = torch.empty(rows, device=dev, dtype=torch.float32)
             y16 = _side16_alloc(ycat.shape, Ncat, dev)
@@ -1246,7 +1278,8 @@ class _ConvGroup1d(Function):
             _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta),
                                                 None if only16 else _p(y), Ncat,
                                                 _p(mean), _p(rstd), rows, Ncat, ln_eps, ACT_GELU,
-                                                _p(y16), Ncat, _stream()), "ac_layernorm_fwd")
+                                                _p(y16), Ncat, 1 if cat16 else 0, _stream()),
+                       "ac_layernorm_fwd")
             if only16:
                 _mark16only(y, y16)
             elif y16 is not None:
@@ -1299,13 +1332,14 @@ class _ConvGroup1d(Function):
                 dyop = torch.empty(B * L, Ncat, device=dev, dtype=torch.bfloat16)
                 out16 = dyop
             else:
-                dpre, out16 = torch.empty_like(ycat), None
+                dpre, out16 = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32), None
             _lib.check(_lib_().ac_layernorm_bwd(_p(dy16in if dy16in is not None else dycat), Ncat,
                                                 _p(ycat), Ncat, _p(mean), _p(rstd),
                                                 _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
                                                 _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
                                                 _p(out16), Ncat, seg[0], seg[1], seg[2],
-                                                1 if dy16in is not None else 0, _stream()),
+                                                1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
+                                                _stream()),
                        "ac_layernorm_bwd")
             dycat = dpre
             if ln_direct:

@@ -86,15 +86,16 @@ class KernelTimer:
     def wrap_conv_window(self, H):
         orig = H.conv_window
 
-        def timed(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+        def timed(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
             if not self.enabled:
-                return orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+                return orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            ok = orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+            ok = orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
             e.record()
             if ok:
-                byts = 2.0 * B * (L + k - 1) * Cw + 2.0 * N * k * Cw + 4.0 * B * L * N * (2 if acc else 1)
+                out_b = (4.0 * (2 if acc else 1) if c_ptr is not None else 0.0) + (2.0 if kw.get("c16_ptr") else 0.0)
+                byts = 2.0 * B * (L + k - 1) * Cw + 2.0 * N * k * Cw + out_b * B * L * N
                 self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw, byts))
             return ok
         H.conv_window = timed

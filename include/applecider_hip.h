@@ -72,7 +72,8 @@ const char *ac_strerror(int code);
  *   if colscale: v *= colscale[n];
  *   if drop_p > 0: v = keep(drop_seed, m*N + n) ? v/(1-drop_p) : 0   (ac_dropout's generator);
  *   if residual: v += residual[m,n];
- *   if c16: c16[m,n] = bf16(v)  (row-major, ld_c16; c.ptr may then be NULL: bf16-only output);
+ *   if c16: c16[m,n] = bf16(v)  (row stride ld_c16, columns through c.goff when that is set;
+ *           c.ptr may then be NULL: bf16-only output);
  *   accumulate: 0 store, 1 C += v, 2 atomicAdd(C, v)  (2 is forced by split_k > 1).
  * mask16 is a bf16 matrix: with act = RELU (and dropout) in the forward product, the forward's bf16
  * output is its own backward mask — alpha = 1/(1-p) then rebuilds dropout's scale
@@ -163,6 +164,9 @@ typedef struct ac_convwin_desc {
     const float *bias;
     int32_t accumulate; /* 0 store, 1 out += */
     int32_t variant;    /* 0 auto; 1: never use the 8-wave two-group kernel for N <= 64 (A/B tests) */
+    void *c16;          /* nullable: bf16 output (element (b, l, n) at c16 + (b*L + l)*ldc16 + n);
+                           c may then be NULL (bf16-only output, accumulate must be 0) */
+    int64_t ldc16;
 } ac_convwin_desc;
 int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
 
@@ -177,15 +181,18 @@ int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
  * ---------------------------------------------------------------------- */
 int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
                      float *y, int64_t ldy, float *mean, float *rstd, int64_t rows, int32_t C,
-                     float eps, int32_t act, void *y16, int64_t ldy16, ac_stream_t stream);
+                     float eps, int32_t act, void *y16, int64_t ldy16, int32_t x_bf16,
+                     ac_stream_t stream);
 /* y16 (nullable): bf16 copy of the output for the matrix product that follows (y may then be NULL);
- * available when C = 4*G*J with G in {8,16,32,64}, J in {1,2,3,6} (AC_EALIGN otherwise). */
+ * available when C = 4*G*J with G in {8,16,32,64}, J in {1,2,3,6} (AC_EALIGN otherwise).
+ * x_bf16 != 0 (both directions, same C restriction): x points at a bf16 matrix (ldx in elements) —
+ * the conv-bank output kept in bf16 between the Conv1d products and LayerNorm. */
 int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
                      float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
                      int64_t rows, int32_t C, int32_t act, void *dx16, int64_t lddx16,
                      int32_t seg_len, int32_t seg_pitch, int32_t seg_off, int32_t dy_bf16,
-                     ac_stream_t stream);
+                     int32_t x_bf16, ac_stream_t stream);
 /* dx16 (nullable, same C restriction as y16; dx may then be NULL): bf16 copy of dx.  With
  * seg_len > 0 row r = (b, l), l < seg_len, is written to row b*seg_pitch + seg_off + l of dx16 —
  * the zero-padded [B, Lp, C] operand of the Conv1d gradient products (pads are the caller's).

@@ -846,3 +846,39 @@ def test_conv_bank_bf16_handover(dev, bf16_mode):
     close(a[0], b[0], tol=0, name="forward")
     for i, (u, v) in enumerate(zip(a[1:], b[1:])):
         close(u, v, tol=1e-2, name=f"grad{i}")
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 1, 64, (3, 61, 1021)), (3, 512, 64, 128, (3, 31, 251)),
+                                             (2, 256, 128, 256, (3, 15, 61)), (2, 64, 256, 64, (3, 11, 31))])
+def test_conv_bank_bf16_cat_buffer(dev, bf16_mode, B, L, Cin, Cout, ks):
+    """bf16 mode keeps the concatenated conv outputs (the LayerNorm input) in bf16.  Against the fp32
+    cat buffer the difference must be one bf16 rounding of the LayerNorm input; against torch (fp32 on
+    bf16-rounded x / w) the usual bf16-mode tolerance."""
+    from applecider_amd import hipops as H
+    rb = lambda t: t.bfloat16().float()
+    x = rb(g(dev, B, L, Cin, seed=1))
+    ws = [rb(g(dev, Cout, k * Cin, seed=10 + i) / math.sqrt(Cin * k)) for i, k in enumerate(ks)]
+    bs = [g(dev, Cout, seed=20 + i) for i in range(3)]
+    gam, bet = 1 + 0.1 * g(dev, 3 * Cout, seed=30), 0.1 * g(dev, 3 * Cout, seed=31)
+    go = g(dev, B, L, 3 * Cout, seed=50)
+    t = lambda a, rg=True: a.detach().to(dev).requires_grad_(rg)
+
+    def run(cat16):
+        H._CAT16 = cat16
+        try:
+            leaves = [t(x, Cin != 1)] + [t(w) for w in ws] + [t(b) for b in bs] + [t(gam), t(bet)]
+            y = H.conv_group1d(leaves[0], ks, leaves[1:4], leaves[4:7], ln=(leaves[7], leaves[8], 1e-5))
+            y.backward(go.to(dev))
+            return [y.detach()] + [l.grad for l in leaves if l.grad is not None]
+        finally:
+            H._CAT16 = True
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        close(u, v, tol=2e-2, name=f"cat16 vs fp32 cat buffer, tensor {i}")
+    # torch reference of the forward (channels-first convs on the rounded operands)
+    xr = x.permute(0, 2, 1)
+    ycat = torch.cat([F.conv1d(xr, w.reshape(Cout, k, Cin).permute(0, 2, 1), bb, padding=k // 2)
+                      for w, bb, k in zip(ws, bs, ks)], 1).permute(0, 2, 1)
+    ref = F.gelu(F.layer_norm(ycat, (3 * Cout,), gam, bet, 1e-5))
+    close(a[0], ref, tol=2e-2, name="forward vs torch")

@@ -306,7 +306,7 @@ def test_cabi_exports_every_declared_symbol():
     assert b"invalid" in loaded.ac_strerror(-22)
     # argument validation happens before any launch, so it can be exercised without a GPU
     assert loaded.ac_gemm(None, None) == -22
-    assert loaded.ac_layernorm_fwd(None, 0, None, None, None, 0, None, None, 1, 4, 1e-5, 0, None, 0, None) == -22
+    assert loaded.ac_layernorm_fwd(None, 0, None, None, None, 0, None, None, 1, 4, 1e-5, 0, None, 0, 0, None) == -22
 
 
 def test_product_refuses_cpu_tensors():

@@ -36,11 +36,11 @@ def tg(mode, M, N, K, a, b, c, **kw):
     recs.setdefault(key, []).append((s, e, 2.0 * M * N * K))
 
 
-def tw(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+def tw(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
     if not on[0]:
-        return ow(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+        return ow(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(); ok = ow(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc); e.record()
+    s.record(); ok = ow(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw); e.record()
     if ok:
         recs.setdefault(("WIN", Bn * L, N, k * Cw, "f" if flip else "-", 1), []).append((s, e, 2.0 * Bn * L * N * k * Cw))
     return ok
