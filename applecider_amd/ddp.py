@@ -9,23 +9,62 @@ Design for MI355X: gradients already live in ONE contiguous fp32 buffer (appleci
 bucket is just a slice of it — no packing copies, few large collectives (xGMI rings are per-link
 bound, so bigger messages amortise the ~10 us launch/latency floor).  Buckets are cut at parameter
 boundaries in buffer order; a bucket is launched from autograd's post-accumulate hooks as soon as
-every parameter in it has its gradient, i.e. while the rest of backward is still running (RCCL runs
-on its own stream and only waits for the work queued so far).  `finish()` launches whatever is left
-(parameters that received no gradient), waits, and averages on the device.
+every parameter in it has its gradient, i.e. while the rest of backward is still running.
+`finish()` launches whatever is left (parameters that received no gradient), waits, and averages on
+the device.
+
+Stream ordering.  The three encoders of the fused model run on three HIP streams, and autograd
+replays a backward node on the stream of its forward, so ONE bucket is written from several streams
+(bucket boundaries are byte counts, not branch boundaries).  Every gradient report therefore records
+an event on the stream that wrote it; the collective of a bucket is issued on a dedicated exchange
+stream that first waits for the latest event of every writer stream of that bucket.  No compute stream
+ever waits for another branch on behalf of the exchange (the branches keep overlapping), and the
+collective cannot start before the last split-K atomic of any branch has landed.
 """
 
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
 
+class _CudaStreamOps:
+    """The three stream primitives the bucket launcher needs (tests substitute a recorder)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.exchange = torch.cuda.Stream(device=device)
+
+    def current_key(self):
+        """Identity of the stream the calling autograd node runs on (hashable)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def record(self, event=None):
+        """(Re-)record `event` on the current stream; returns it."""
+        if event is None:
+            event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(self.device))
+        return event
+
+    def exchange_wait(self, event):
+        self.exchange.wait_event(event)
+
+    def on_exchange(self):
+        return torch.cuda.stream(self.exchange)
+
+    def join_exchange(self):
+        """Current stream waits for everything queued on the exchange stream."""
+        torch.cuda.current_stream(self.device).wait_stream(self.exchange)
+
+
 class GradBuckets:
     def __init__(self, flat_params, process_group=None, bucket_bytes: int = 32 << 20,
-                 overlap: bool = True):
-        """flat_params: applecider_amd.optim.FlatParameters (already flattened)."""
+                 overlap: bool = True, stream_ops=None):
+        """flat_params: applecider_amd.optim.FlatParameters (already flattened).
+        stream_ops: object with the _CudaStreamOps interface (default: real HIP streams when the
+        gradient buffer is on a GPU, none on CPU)."""
         self.fp = flat_params
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -37,9 +76,13 @@ class GradBuckets:
         self.handles: list = []
         self.launched: List[bool] = []
         self._hooks = []
+        self.ops = stream_ops
+        if self.ops is None and self.fp.grad is not None and self.fp.grad.is_cuda:
+            self.ops = _CudaStreamOps(self.fp.grad.device)
         self._build(bucket_bytes // 4)
         self._inv_world = None
-        if self.world > 1:
+        self.last_wait_log: List[tuple] = []
+        if self.world > 1 or stream_ops is not None:
             self._index = {id(p): i for i, p in enumerate(self.fp.params)}
             for i, p in enumerate(self.fp.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -64,6 +107,8 @@ class GradBuckets:
                 self.counts.append(count)
                 begin, n, count = off + sz, 0, 0
                 cur += 1
+        # one reusable event per (bucket, writer stream): re-recorded every step
+        self._events: List[Dict[object, object]] = [dict() for _ in self.buckets]
         self.reset()
 
     def reset(self):
@@ -72,6 +117,11 @@ class GradBuckets:
         self.pending = list(self.counts)
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self._writers: List[set] = [set() for _ in self.buckets]
+        self.wait_log = []                  # (bucket, writer-stream keys waited for) of this backward
+
+    def _all_reduce(self, view):
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch(self, b: int):
         if self.launched[b]:
@@ -79,43 +129,61 @@ class GradBuckets:
         self.launched[b] = True
         lo, hi = self.buckets[b]
         view = self.fp.grad[lo:hi]
-        if view.is_cuda:
-            # a bucket mixes parameters of branches that run on different streams: the collective
-            # (which orders itself after the CURRENT stream only) must see all their gradients
-            from . import hipops as H
-            H.wait_side_streams()
-        self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
-                                            async_op=True))
+        ops = self.ops
+        if ops is None:
+            self.handles.append(self._all_reduce(view))
+            return
+        # the exchange stream waits for the last gradient write of EVERY stream that wrote into this
+        # bucket (events recorded at report time), and for the launching stream's work so far (covers
+        # parameters that never reported: their slice was zeroed on that stream)
+        writers = sorted(self._writers[b], key=repr)
+        for key in writers:
+            ops.exchange_wait(self._events[b][key])
+        ops.exchange_wait(ops.record())
+        self.wait_log.append((b, tuple(writers)))
+        with ops.on_exchange():
+            self.handles.append(self._all_reduce(view))
+
+    def _report(self, idx: int):
+        # A parameter is counted once per backward: a gradient written through a sink is reported by
+        # the kernel wrapper, and autograd still runs the parameter's post-accumulate hook afterwards
+        # (with an undefined gradient) - the first report wins.
+        if idx in self._seen:
+            self.duplicates.append(idx)
+            return
+        self._seen.add(idx)
+        b = self.bucket_of[idx]
+        if self.ops is not None:
+            key = self.ops.current_key()
+            self._events[b][key] = self.ops.record(self._events[b].get(key))
+            self._writers[b].add(key)
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and self.overlap:
+            self._launch(b)
 
     def _make_hook(self, idx: int):
         def hook(_param):
-            # A parameter is counted once per backward: a gradient written through a sink is
-            # reported by the kernel wrapper, and autograd still runs the parameter's
-            # post-accumulate hook afterwards (with an undefined gradient) - the first report wins.
-            if idx in self._seen:
-                self.duplicates.append(idx)
-                return
-            self._seen.add(idx)
-            b = self.bucket_of[idx]
-            self.pending[b] -= 1
-            if self.pending[b] == 0 and self.overlap:
-                self._launch(b)
+            self._report(idx)
         return hook
 
     def _on_sink(self, param):
         i = self._index.get(id(param))
         if i is not None:
-            self._make_hook(i)(param)
+            self._report(i)
 
     def finish(self):
         """Call after backward(): completes the exchange and leaves the AVERAGED gradient in the
         flat buffer.  No host synchronisation on GPU (stream waits only)."""
-        if self.world == 1:
+        if self.world == 1 and self.ops is None:
             return
         for b in range(len(self.buckets)):
             self._launch(b)
+        self.last_wait_log = list(self.wait_log)
         for h in self.handles:
-            h.wait()
+            if h is not None:
+                h.wait()
+        if self.ops is not None:
+            self.ops.join_exchange()
         g = self.fp.grad
         if g.is_cuda:
             from . import hipops as H
@@ -140,7 +208,10 @@ class GradBuckets:
 
 
 def init_from_env(backend: Optional[str] = None):
-    """One process per GPU, rendezvous from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+    """One process per GPU, rendezvous from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun).
+    Also offsets this rank's dropout seed stream: every rank calls torch.manual_seed with the same
+    value (identical initial weights before the broadcast), but the replicas must not draw identical
+    dropout masks."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -151,7 +222,20 @@ def init_from_env(backend: Optional[str] = None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    try:
+        from . import hipops as H
+        H.set_seed_offset(rank)
+    except Exception:  # CPU-only unit tests without the shared library
+        pass
     return rank, local, world
+
+
+def rccl_ranks() -> int:
+    """Number of ranks of the live RCCL (backend "nccl") communicator; 0 when the job does not run
+    over RCCL (single process, or a gloo rehearsal)."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return dist.get_world_size()
+    return 0
 
 
 def broadcast_parameters(flat_params, src: int = 0, process_group=None):

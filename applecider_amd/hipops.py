@@ -69,6 +69,10 @@ def _chk(t: torch.Tensor, name="tensor", allow16: bool = False):
                            "between two kernels); its consumer must read the bf16 side tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: applecider_amd kernels need a GPU tensor (no CPU fallback)")
+    if _DEV_INDEX is not None and t.device.index != _DEV_INDEX:
+        raise RuntimeError(f"{name}: tensor lives on cuda:{t.device.index} but this process launches on "
+                           f"cuda:{_DEV_INDEX} (one process drives one GPU: call torch.cuda.set_device "
+                           "before the first kernel)")
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
@@ -381,12 +385,21 @@ def _tn_plan(m_out: int, n_out: int, k_red: int):
 
 
 _seed_counter = itertools.count(1)
+_seed_offset = 0
+
+
+def set_seed_offset(rank: int):
+    """Decorrelates the dropout streams of data-parallel replicas that share torch's global seed
+    (ddp.init_from_env calls this with the rank)."""
+    global _seed_offset
+    _seed_offset = int(rank)
 
 
 def next_seed() -> int:
-    """Fresh dropout seed derived from torch's global seed (deterministic per process)."""
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) \
-        & 0xFFFFFFFFFFFFFFFF
+    """Fresh dropout seed derived from torch's global seed, the replica's rank and a per-process
+    counter (deterministic per process)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03
+            + _seed_offset * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 _table_cache: dict = {}

@@ -139,6 +139,47 @@ class KernelTimer:
         return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(argv, gpus: int, port: int):
+    """The command `python bench.py --gpus N ...` turns itself into when it is started as a plain
+    process (no WORLD_SIZE in the environment): one rank per GPU under torch.distributed.run, local
+    rendezvous on 127.0.0.1 (the driver's own multi-GPU form)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """Parent of an N > 1 run started without torchrun: starts the ranks as a CHILD process tree
+    (never exec: this process has not touched the GPU and never will), relays rank 0's JSON line and
+    returns non-zero if any rank failed."""
+    import subprocess
+    cmd = launch_command([a for a in argv if a != "--dry-run-launch"], args.gpus, _free_port())
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +200,17 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 over gloo "
                          "(a one-GPU box cannot host an RCCL communicator with two ranks)")
+    ap.add_argument("--force-branch-streams", action="store_true",
+                    help="with --rehearse-one-gpu: keep the three encoder streams (slow when two processes "
+                         "share one GPU; used for a single step to exercise the exchange-stream ordering)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command "
+                         "instead of starting it (launcher plumbing test, no GPU needed)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher before anything touches the GPU
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     from applecider_amd import ddp, hipops as H
     from applecider_amd.config import default_config
@@ -172,14 +223,15 @@ def main():
     else:
         rank, local, world = ddp.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     H.set_math(args.math)
 
     torch.manual_seed(1234)
     model = AppleCider(dict(FUSION_CFG)).to(dev).train()
-    if args.no_branch_streams or args.rehearse_one_gpu or os.environ.get("APPLECIDER_BRANCH_STREAMS") == "0":
+    if (args.no_branch_streams or (args.rehearse_one_gpu and not args.force_branch_streams)
+            or os.environ.get("APPLECIDER_BRANCH_STREAMS") == "0"):
         # (two processes sharing ONE GPU, as in the rehearsal mode, time-slice its hardware queues:
         # with three streams per process a step took seconds)
         model.branch_streams = False
@@ -253,6 +305,7 @@ def main():
         timer.enabled = False
         model.branch_streams = was_streams
 
+    rccl_ranks = ddp.rccl_ranks()
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -323,7 +376,7 @@ def main():
     out = {
         "metric": "multimodal samples/sec/GPU (fwd+bwd) at batch 512; 1->8 GPU scaling",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full 4-modality AppleCiDEr (image 3x63x63 + metadata 24 "

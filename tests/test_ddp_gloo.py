@@ -95,3 +95,102 @@ def test_bucket_layout_covers_buffer():
         assert p.data_ptr() == fp.flat.data_ptr() + 4 * off
         assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * off
     assert fp.is_current()
+
+
+class _FakeStreamOps:
+    """Stands in for ddp._CudaStreamOps on CPU: `current` names the stream the 'kernel wrapper' runs
+    on; events remember the stream they were recorded on; the exchange stream logs what it waits for."""
+
+    def __init__(self):
+        self.current = "main"
+        self.waited = []          # stream names the exchange stream was told to wait for, in order
+        self.on_exchange_calls = 0
+
+    def current_key(self):
+        return self.current
+
+    def record(self, event=None):
+        event = event if event is not None else {}
+        event["stream"] = self.current
+        return event
+
+    def exchange_wait(self, event):
+        self.waited.append(event["stream"])
+
+    def on_exchange(self):
+        import contextlib
+        self.on_exchange_calls += 1
+        return contextlib.nullcontext()
+
+    def join_exchange(self):
+        pass
+
+
+def test_bucket_collective_waits_for_every_writer_stream():
+    """A bucket whose parameters got their gradients from kernels on different streams must order
+    its collective after ALL of them (the main stream was never waited for)."""
+    from applecider_amd.ddp import GradBuckets
+    from applecider_amd.optim import FlatParameters
+    ps = [torch.nn.Parameter(torch.randn(64)) for _ in range(6)]
+    fp = FlatParameters([{"params": ps}])
+    fp.flatten()
+    ops = _FakeStreamOps()
+
+    class GB(GradBuckets):
+        def _all_reduce(self, view):
+            self.reduced = getattr(self, "reduced", []) + [(view.data_ptr(), view.numel(), list(ops.waited))]
+            return None
+
+    gb = GB(fp, bucket_bytes=4 * 128, stream_ops=ops)      # 2 parameters per bucket -> 3 buckets
+    assert len(gb.buckets) == 3
+    # bucket 0: spectra branch (main) then photometry stream; bucket 1: image stream only;
+    # bucket 2: one parameter from the image stream, one never reports (no gradient)
+    for idx, stream in ((0, "main"), (1, "s_pho"), (2, "s_img"), (3, "s_img"), (4, "s_img")):
+        ops.current = stream
+        gb._report(idx)
+    assert [b for b, _ in gb.wait_log] == [0, 1]
+    assert gb.wait_log[0] == (0, ("main", "s_pho"))
+    assert gb.wait_log[1] == (1, ("s_img",))
+    # the collective of bucket 0 was issued from s_pho's hook but waited for main's event as well
+    assert set(gb.reduced[0][2]) == {"main", "s_pho"}
+    ops.current = "main"
+    ops.waited.clear()
+    gb.finish()                                            # launches bucket 2 from the main stream
+    assert gb.last_wait_log[-1] == (2, ("s_img",))
+    assert "s_img" in gb.reduced[2][2] and "main" in gb.reduced[2][2]
+    assert ops.on_exchange_calls == 3
+    # a second report of the same parameter in one backward (sink + autograd hook) is ignored
+    gb._report(0)
+    gb._report(0)
+    assert gb.duplicates == [0]
+    gb.remove()
+
+
+def test_rank_offsets_dropout_seed():
+    from applecider_amd import hipops as H
+    torch.manual_seed(1234)
+    H.set_seed_offset(0)
+    a = H.next_seed()
+    H.set_seed_offset(3)
+    b = H.next_seed()
+    H.set_seed_offset(0)
+    assert a != b and (b - a) % (1 << 64) != 0xD1B54A32D192ED03   # not just the counter step
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus N` without WORLD_SIZE becomes the torch.distributed.run launcher."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7",
+                          "--warmup", "2", "--dry-run-launch"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]

@@ -108,7 +108,19 @@ def _worker_body(rank, world, port, q, overlap, sinks, fused):
     # model owns parameters that are not on its path — e.g. the unused photometry class head — whose
     # buckets are launched by finish())
     assert len(gb._seen) == len(opt.fp.params) or fused
+    main_key = torch.cuda.current_stream(dev).cuda_stream
     gb.finish()
+    # stream ordering of the exchange: every bucket waited for each stream that wrote into
+    # it.  The fused model's encoders run on three streams: the spectra branch on the caller's stream,
+    # image and photometry on side streams, and 8 MB buckets mix them.
+    log = gb.last_wait_log
+    assert sorted(b for b, _ in log) == list(range(len(gb.buckets)))
+    if fused:
+        streams = set(k for _, w in log for k in w)
+        assert len(streams) == 3 and main_key in streams, (streams, main_key)
+        assert any(len(w) > 1 for _, w in log), "no bucket mixed gradients of two branches"
+    else:
+        assert all(w in ((main_key,), ()) for _, w in log)
     torch.cuda.synchronize()
     q.put((rank, opt.fp.grad.cpu().numpy().copy(), float(loss.item())))
     dist.barrier()
