@@ -64,10 +64,19 @@ class PinnedStager:
     """Double-buffered pinned-host staging + async H2D on a copy stream.
 
         stager = PinnedStager(device)
-        dev_batch = stager.stage(host_tuple)    # returns device tensors; copy overlaps compute
+        dev_batch = stager.stage(host_tuple)          # copy, then make the current stream wait for it
+    or, to overlap the copy of batch i+1 with the compute of batch i:
+        ticket = stager.prefetch(host_tuple_next)     # copies are queued on the copy stream only
+        ... launch step i ...
+        dev_batch = stager.acquire(ticket)            # the current stream waits for the copy event
 
-    The returned tensors are safe to use on the current stream: the stage records an event on the
-    copy stream and the current stream waits on it (no host synchronisation).
+    The returned tensors are safe to use on the stream that called acquire()/stage(): the copy stream
+    records an event after the last copy and that stream waits on it (no host synchronisation); the
+    tensors are marked as used by it so the caching allocator does not hand their memory back to
+    the copy stream early.  A slot's pinned buffers are rewritten only after the event of their
+    previous copy has completed (host-side wait on that one event, `depth` batches later).
+    Entries of `host_tuple` that already are pinned torch tensors (a loader that collates straight
+    into pinned memory) are copied from directly.
     """
 
     def __init__(self, device, depth: int = 2):
@@ -77,9 +86,15 @@ class PinnedStager:
         self.host = [dict() for _ in range(depth)]
         self.events = [None] * depth
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.bytes_staged = 0
 
-    def _pinned(self, slot, key, arr: np.ndarray):
-        t = torch.from_numpy(np.ascontiguousarray(arr))
+    def _pinned(self, slot, key, arr):
+        if torch.is_tensor(arr):
+            if arr.is_pinned():
+                return arr
+            t = arr.contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(arr))
         buf = self.host[slot].get(key)
         if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
             buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=self.device.type == "cuda")
@@ -87,21 +102,36 @@ class PinnedStager:
         buf.copy_(t)
         return buf
 
-    def stage(self, host_tuple):
+    def prefetch(self, host_tuple):
+        """Queue the H2D copies of one batch on the copy stream; returns a ticket for acquire()."""
         slot = self.slot
         self.slot = (self.slot + 1) % self.depth
         if self.events[slot] is not None:
-            self.events[slot].synchronize()  # pinned buffer of this slot is free again
+            self.events[slot].synchronize()  # pinned buffers of this slot are free again
         if self.copy_stream is None:
-            return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in host_tuple)
+            return (None, tuple(a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+                                for a in host_tuple))
         outs = []
         with torch.cuda.stream(self.copy_stream):
             for i, a in enumerate(host_tuple):
-                outs.append(self._pinned(slot, i, a).to(self.device, non_blocking=True))
+                src = self._pinned(slot, i, a)
+                self.bytes_staged += src.numel() * src.element_size()
+                outs.append(src.to(self.device, non_blocking=True))
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self.events[slot] = ev
-        torch.cuda.current_stream(self.device).wait_event(ev)
+        return (ev, tuple(outs))
+
+    def acquire(self, ticket):
+        """Order the current stream after the ticket's copies and hand out the device tensors."""
+        ev, outs = ticket
+        if ev is None:
+            return outs
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
         for o in outs:
-            o.record_stream(torch.cuda.current_stream(self.device))
-        return tuple(outs)
+            o.record_stream(cur)
+        return outs
+
+    def stage(self, host_tuple):
+        return self.acquire(self.prefetch(host_tuple))

@@ -111,8 +111,12 @@ class SpectraNet(nn.Module):
         return out.squeeze(1) if self.redshift else out
 
     def train_step(self, batch):
-        """Uses self.optimizer / self.criterion injected by Hyrax (spectranet.py:172-184); with no
-        injection, `applecider_amd.training.attach_defaults(model)` sets SGD(0.01, 0.9) + CE."""
+        """Uses self.optimizer / self.criterion injected by Hyrax (spectranet.py:172-184); without
+        Hyrax, `applecider_amd.training.attach_defaults(model)` sets its defaults, SGD(0.01, 0.9) +
+        CrossEntropyLoss.  Labels arrive as int16 (to_tensor, spectranet.py:204)."""
+        if not hasattr(self, "optimizer") or not hasattr(self, "criterion"):
+            raise AttributeError("SpectraNet.train_step needs self.optimizer and self.criterion (Hyrax "
+                                 "injects them; standalone: applecider_amd.training.attach_defaults(model))")
         _, labels, redshifts = batch
         self.optimizer.zero_grad()
         outputs = self(batch)

@@ -188,7 +188,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="SURVEY section 8(d): B = 32 for the full model on CPU")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="also bracket every matrix-core launch of the TIMED region with HIP events (each "
@@ -200,6 +201,9 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 over gloo "
                          "(a one-GPU box cannot host an RCCL communicator with two ranks)")
+    ap.add_argument("--h2d", action="store_true",
+                    help="after the timed region, time the same steps again with every batch staged from "
+                         "pinned host memory through PinnedStager and report it as `pcie_inclusive`")
     ap.add_argument("--force-branch-streams", action="store_true",
                     help="with --rehearse-one-gpu: keep the three encoder streams (slow when two processes "
                          "share one GPU; used for a single step to exercise the exchange-stream ordering)")
@@ -246,10 +250,11 @@ def main():
     batch = tuple(torch.from_numpy(b[k]).to(dev) for k in
                   ("photometry", "pad_mask", "metadata", "image", "spectra", "label"))
 
-    def step():
+    def step(bt=None):
+        bt = batch if bt is None else bt
         opt.zero_grad()
-        logits = model(*batch[:5])
-        loss = H.cross_entropy_index(logits, batch[5])
+        logits = model(*bt[:5])
+        loss = H.cross_entropy_index(logits, bt[5])
         loss.backward()
         if gb is not None:
             gb.finish()
@@ -283,6 +288,42 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+
+    # PCIe-inclusive rate (never `value`): every step's batch starts in pinned host memory (where a
+    # loader's collate leaves it) and is staged by PinnedStager — async H2D on a copy stream, one batch
+    # ahead of the compute stream (datasets/collate.py).
+    h2d = None
+    if args.h2d:
+        from applecider_amd.datasets.collate import PinnedStager
+        keys = ("photometry", "pad_mask", "metadata", "image", "spectra", "label")
+        hosts = []
+        for j in range(2):
+            hb = make_batch(B, seed=2 + 1000 * rank + 17 * j)
+            hosts.append(tuple(torch.from_numpy(np.ascontiguousarray(hb[k])).pin_memory() for k in keys))
+        stager = PinnedStager(dev, depth=2)
+        ticket = stager.prefetch(hosts[0])
+        for i in range(2):                                   # untimed: allocator + pipeline fill
+            cur, ticket = stager.acquire(ticket), stager.prefetch(hosts[(i + 1) % 2])
+            step(cur)
+        torch.cuda.synchronize()
+        barrier()
+        staged0 = stager.bytes_staged
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            cur, ticket = stager.acquire(ticket), stager.prefetch(hosts[(i + 1) % 2])
+            step(cur)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        h2d = {"value": round(world * B * args.steps / el, 2), "unit": "samples/s",
+               "ms_per_step": round(el / args.steps * 1e3, 3),
+               "h2d_bytes_per_step": (stager.bytes_staged - staged0) // args.steps,
+               "how": "batches start in pinned host memory; PinnedStager prefetches batch i+1 on a copy "
+                      "stream while step i runs (double-buffered, event-ordered, no host sync)"}
 
     peak = PEAK_TFLOPS[args.math]
     ks_timed = timer.summary(peak * 1e12, HBM_PEAK_GBS * 1e9)
@@ -362,6 +403,9 @@ def main():
                     roofline["traffic"] = round(v["per_launch_MB"] * 1e6)
                     roofline["traffic_unit"] = ("bytes per launch, average over ALL launches of this kernel "
                                                 "(fabric-side FETCH+WRITE, PMC)")
+                    roofline["traffic_source"] = ("profiles/r01_pmc_hbm_traffic.json (committed rocprofv3 --pmc "
+                                                  "passes of this command, separate FETCH_SIZE / WRITE_SIZE runs, "
+                                                  "FETCH_SIZE doubled for gfx950); NOT measured in this run")
                     break
     except Exception:
         pass
@@ -386,6 +430,8 @@ def main():
                    "encoder_streams": 3 if model.branch_streams else 1},
         "roofline": roofline,
     }
+    if h2d is not None:
+        out["pcie_inclusive"] = h2d
     if other is not None:
         out["roofline_other_class"] = other
     if "dwconv7x7_fwd" in ks:
@@ -402,7 +448,7 @@ def main():
         sd = closed_form_state_dict({k: v.shape for k, v in cpu_model.state_dict().items()})
         ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": "avg", "lr": 1e-3,
                 "kernel_sizes_per_stage": default_config()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
-        res = time_full_model(sd, cb, ocfg, steps=2, warmup=1)
+        res = time_full_model(sd, cb, ocfg, steps=max(3, args.cpu_steps), warmup=1)
         res["value"] = round(res["value"], 3)
         res["ms_per_step"] = round(res["ms_per_step"], 1)
         out["cpu_baseline"] = res

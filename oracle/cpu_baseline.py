@@ -30,8 +30,22 @@ def usable_cores() -> int:
     return min(n, 16)  # a 1-GPU box's CPU share
 
 
-def time_full_model(state_dict: dict, batch: dict, cfg: dict, steps: int = 2, warmup: int = 1,
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def time_full_model(state_dict: dict, batch: dict, cfg: dict, steps: int = 3, warmup: int = 1,
                     threads: int | None = None) -> dict:
+    """fp32, all usable cores, 1 warm-up + >= 3 timed steps, both
+    (i) forward only and (ii) forward + CrossEntropy + backward + Adam step; `value` is (ii)."""
+    import sys
     threads = threads or usable_cores()
     torch.set_num_threads(threads)
     params = {k: v.clone().requires_grad_() for k, v in state_dict.items()}
@@ -48,7 +62,10 @@ def time_full_model(state_dict: dict, batch: dict, cfg: dict, steps: int = 2, wa
         opt.step()
         return float(loss.detach())
 
-    import sys
+    def fwd():
+        with torch.no_grad():
+            return O.applecider_forward(params, *args, cfg)
+
     for _ in range(warmup):
         t = time.perf_counter()
         step()
@@ -60,6 +77,12 @@ def time_full_model(state_dict: dict, batch: dict, cfg: dict, steps: int = 2, wa
         print(f"[cpu_baseline] timed step {i + 1}/{steps} at {time.perf_counter() - t0:.1f}s",
               file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / steps
+    fwd()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fwd()
+    dtf = (time.perf_counter() - t0) / steps
     return {"value": B / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32 fwd+CE+bwd+Adam, batch {B}, {steps} timed steps after {warmup} warm-up",
-            "ms_per_step": dt * 1e3}
+            "ms_per_step": dt * 1e3, "cpu_model": cpu_model(),
+            "fwd_only": {"value": round(B / dtf, 3), "unit": "samples/s", "ms_per_step": round(dtf * 1e3, 1)}}

@@ -264,6 +264,26 @@ def spectranet_forward(sd, x, kernel_sizes_per_stage, depths=None, head="classif
     return (out, stages) if return_stages else out
 
 
+def spectranet_train_steps(sd, flux, labels, kernel_sizes_per_stage, n_steps=1, lr=0.01, momentum=0.9):
+    """SpectraNet.train_step (spectranet.py:172-184) under the optimizer / criterion Hyrax injects
+    (torch.optim.SGD(lr, momentum), CrossEntropyLoss; spectranet_testing.ipynb cell 14), restated on a
+    state_dict: zero_grad -> forward -> CE -> backward -> buf = momentum*buf + g ; p -= lr*buf
+    (torch.optim.SGD: the first step initialises buf = g).  Labels may be any integer dtype (the
+    reference's to_tensor emits int16, spectranet.py:204).  Returns (losses, updated state_dict)."""
+    sd = {k: v.detach().clone().requires_grad_() for k, v in sd.items()}
+    buf, losses = {}, []
+    for _ in range(n_steps):
+        logits = spectranet_forward(sd, flux, kernel_sizes_per_stage)
+        loss = F.cross_entropy(logits, labels.long())
+        grads = torch.autograd.grad(loss, list(sd.values()))
+        losses.append(float(loss.detach()))
+        with torch.no_grad():
+            for (k, p), g in zip(sd.items(), grads):
+                buf[k] = g.clone() if k not in buf else buf[k].mul_(momentum).add_(g)
+                p.sub_(lr * buf[k])
+    return losses, {k: v.detach() for k, v in sd.items()}
+
+
 # ----------------------------------------------------------------------------- F1: fusion
 def fusion_head(sd, p_emb, s_emb, im_emb, fusion="avg"):
     """AppleCider.get_embeddings/forward after the encoders

@@ -108,6 +108,35 @@ def test_spectranet_golden(dev):
     assert_close(norms, g["full.gradnorm_all"], GRAD_TOL, "full grad norms")
 
 
+def test_spectranet_train_step_golden(dev):
+    """C3 (spectranet.py:172-184): train_step under the injected SGD(0.01, 0.9) + CrossEntropyLoss with
+    the int16 labels the reference's to_tensor emits, two steps (momentum buffer), against the
+    reference's own run (golden g10)."""
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    from applecider_amd.training import attach_defaults
+    g = gold("g10_spectranet_step.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    m = attach_defaults(build(SpectraNet, cfg, dev).eval())
+    b = make_batch(4, seed=10, spec_len=256)
+    flux, label, red = SpectraNet.to_tensor({"data": {"flux": b["spectra"], "label": b["label"],
+                                                      "redshift": np.zeros(4, np.float32)}})
+    assert label.dtype == np.int16
+    batch = (T(flux).to(dev), T(label).to(dev), T(red).to(dev))
+    assert batch[1].dtype == torch.int16
+    l1 = m.train_step(batch)["loss"]
+    l2 = m.train_step(batch)["loss"]
+    assert abs(l1 - float(g["loss1"])) <= LOGIT_TOL * abs(float(g["loss1"]))
+    assert abs(l2 - float(g["loss2"])) <= 3e-3 * abs(float(g["loss2"]))   # after one lr=0.01 momentum step
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("after_step2."):
+            assert_close(compact(sd[k[12:]].detach().cpu().numpy()), g[k], 1e-3, k)
+    with torch.no_grad():
+        assert_close(m(batch), g["logits_after_step2"], 5e-3, "logits after two SGD steps")
+
+
 @pytest.mark.parametrize("L", [128, 257])
 def test_baselinecls_golden(dev, L):
     from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS

@@ -85,6 +85,32 @@ def test_g4_spectranet_oracle():
     assert_close(logits, g["full.logits"], TOL, "full logits")
 
 
+def test_g10_spectranet_train_step_oracle():
+    """C3: the reference's SpectraNet.train_step under SGD(0.01, 0.9) + CE, int16 labels from its own
+    to_tensor, two steps (tools/make_goldens.py g10)."""
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    g = gold("g10_spectranet_step.npz")
+    assert str(g["label_dtype"]) == "int16"
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    ks = cfg["model"]["SpectraNet"]["kernel_sizes_per_stage"]
+    sd = closed_form_sd(SpectraNet(cfg))
+    b = make_batch(4, seed=10, spec_len=256)
+    flux, label, _ = SpectraNet.to_tensor({"data": {"flux": b["spectra"], "label": b["label"],
+                                                    "redshift": np.zeros(4, np.float32)}})
+    assert label.dtype == np.int16
+    losses, sd2 = O.spectranet_train_steps(sd, T(flux), T(label), ks, n_steps=2)
+    assert abs(losses[0] - float(g["loss1"])) <= TOL * abs(float(g["loss1"]))
+    assert abs(losses[1] - float(g["loss2"])) <= 5e-5 * abs(float(g["loss2"]))
+    for k in g.files:
+        if k.startswith("after_step2."):
+            assert_close(compact(sd2[k[12:]].numpy()), g[k], 5e-5, k)
+    with torch.no_grad():
+        assert_close(O.spectranet_forward(sd2, T(flux), ks), g["logits_after_step2"], 2e-4, "logits after 2 steps")
+
+
 @pytest.mark.parametrize("L", [128, 257])
 def test_g5_baselinecls_oracle(L):
     from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
@@ -218,6 +244,29 @@ def test_g8_to_tensor_and_collate():
     assert np.array_equal(mask, g["to_tensor.mask"]) and np.array_equal(lab, g["to_tensor.label"])
     with pytest.raises(ValueError):
         HyraxBaselineCLS.to_tensor({"nodata": 1})
+
+
+def test_g11_collate_fused_vs_reference():
+    """(f-1) the 5-modal host collate against the reference's own (Time2Vec.py:18-45) output, with
+    explicit mean/std; padded positions are normalised like the reference does ((0 - mean)/(std+1e-8))."""
+    from applecider_amd.datasets.collate import PinnedStager, collate_fused
+    g = gold("g11_collate_fused.npz")
+    from applecider_amd.synthetic import make_batch
+    b = make_batch(5, seed=11, spec_len=64)
+    batch = [(g[f"seq{i}"], b["metadata"][i], b["image"][i], b["spectra"][i], int(b["label"][i])) for i in range(5)]
+    out = collate_fused(batch, g["mean"], g["std"])
+    names = ("photometry", "photo_mask", "metadata", "images", "spectra", "labels")
+    for name, a in zip(names, out):
+        want = g["out." + name]
+        assert a.shape == want.shape and a.dtype == want.dtype, name
+        if a.dtype == np.float32:
+            assert np.abs(a - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
+        else:
+            assert np.array_equal(a, want), name
+    # CPU stager (no GPU): pass-through tensors with the same values, schema order kept
+    st = PinnedStager("cpu")
+    dev = st.stage(out)
+    assert all(np.array_equal(t.numpy(), a) for t, a in zip(dev, out))
 
 
 def test_to_tensor_contracts():
