@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
 AC_GEMM_NT, AC_GEMM_NN, AC_GEMM_TN = 0, 1, 2
 AC_EINVAL = -22
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-MATH_F32, MATH_BF16, MATH_BF16_IN = 0, 1, 2
+MATH_F32, MATH_BF16, MATH_BF16_IN, MATH_BF16X3 = 0, 1, 2, 3
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU,
              "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH}
 

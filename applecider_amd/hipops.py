@@ -23,14 +23,25 @@ from ._lib import (ACT_CODES, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TAN
 _MATH = _lib.MATH_F32
 
 
+_MATH_NAMES = {"f32": _lib.MATH_F32, "bf16": _lib.MATH_BF16, "bf16x3": _lib.MATH_BF16X3}
+# modes whose logits are held to the path's parity bar (<= 1e-3 relative to the CPU oracle, identical
+# argmax) by tests/test_gpu_parity_modes.py; plain bf16 is the fast, unqualified mode
+QUALIFIED_MODES = ("f32", "bf16x3")
+
+
 def set_math(mode: str):
-    """'f32' (exact fp32 matrix cores) or 'bf16' (bf16 MFMA inputs, fp32 accumulate/storage)."""
+    """Matrix-core arithmetic of every product on the path:
+      'f32'     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), fp32 data flow
+      'bf16x3'  split bf16: fp32 data flow, every product = 3 bf16 MFMAs on (hi, lo) operand halves,
+                ~2^-16 relative per product (the qualified fast mode)
+      'bf16'    bf16 MFMA inputs (one rounding to 8 mantissa bits per operand), bf16 operand copies and
+                bf16-only hand-overs in HBM, fp32 accumulate / parameters / optimizer state"""
     global _MATH
-    _MATH = {"f32": _lib.MATH_F32, "bf16": _lib.MATH_BF16}[mode]
+    _MATH = _MATH_NAMES[mode]
 
 
 def get_math() -> str:
-    return "bf16" if _MATH == _lib.MATH_BF16 else "f32"
+    return {v: k for k, v in _MATH_NAMES.items()}[_MATH]
 
 
 # --------------------------------------------------------------------------- helpers

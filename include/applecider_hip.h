@@ -86,8 +86,12 @@ enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC
 /* MFMA input type.  F32 / BF16: operands are fp32 in memory (BF16 rounds them while staging).
  * BF16_IN: A and B are already bf16 in memory (ac_cast_bf16 / ac_transpose_cast_bf16); strides,
  * goff entries and inner extents are in bf16 elements and multiples of 8; modes NT and TN only.
+ * BF16X3: fp32 operands in memory like F32; each element is split while staging into hi = bf16(x)
+ * and lo = bf16(x - hi), and each product is three bf16 matrix-core instructions (hi*hi + hi*lo +
+ * lo*hi, fp32 accumulate): ~2^-16 relative per product — the mode that meets the path's 1e-3 logit
+ * parity bar at bf16 matrix-core speed.
  * C, bias, aux, residual stay fp32 in every mode. */
-enum { AC_MATH_F32 = 0, AC_MATH_BF16 = 1, AC_MATH_BF16_IN = 2 };
+enum { AC_MATH_F32 = 0, AC_MATH_BF16 = 1, AC_MATH_BF16_IN = 2, AC_MATH_BF16X3 = 3 };
 
 typedef struct ac_rowmap {
     int32_t r1, r2;

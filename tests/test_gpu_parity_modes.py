@@ -1,0 +1,186 @@
+"""Parity of every arithmetic mode of the MI355X path against the CPU oracle at the sizes
+BASELINE.json quotes (VERDICT r1, row a'):
+
+    configs[1]  AstroMiNN (image + metadata), B = 256   -> logits vs oracle.astrominn_forward
+    configs[2]  full 4-modality AppleCiDEr,   B = 512   -> logits vs oracle.applecider_forward
+
+north_star's bar: logits within 1e-3 relative (to the largest logit) of the CPU path and identical
+argmax labels.  'f32' (fp32 MFMA) and 'bf16x3' (split bf16, 3 bf16 MFMAs per product) are the
+QUALIFIED modes and are held to that bar here.  Plain 'bf16' (one rounding of every operand to 8
+mantissa bits, bf16-only hand-overs) is the fast mode: it is measured against the same oracle, held
+to the looser bound stated below, and its argmax agreement is counted and reported — it cannot meet
+1e-3 (SURVEY section 7 "bf16 + argmax parity": top-2 routing on raw sigmoids flips on near-ties).
+
+Every run appends its numbers to gpurun_out/parity_modes.json (copied to profiles/ per round).
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import T, cfg_default, closed_form_sd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUALIFIED_TOL = 1e-3
+BF16_TOL = 6e-2          # stated bound for the unqualified fast mode (measured values in the report)
+FUSED_CFG = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.0,
+             "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3}
+
+
+def _report(key, rec):
+    path = os.path.join(ROOT, "gpurun_out", "parity_modes.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = rec
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[parity] {key}: {rec}")
+
+
+def _compare(logits, ref):
+    got = logits.detach().float().cpu().numpy().astype(np.float64)
+    ref = ref.detach().cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max() / scale
+    agree = int((got.argmax(1) == ref.argmax(1)).sum())
+    # how close the oracle's own top-2 logits are where the labels differ (near-ties)
+    srt = np.sort(ref, axis=1)
+    margin = (srt[:, -1] - srt[:, -2]) / scale
+    flipped = got.argmax(1) != ref.argmax(1)
+    return {"max_rel_err": float(err), "argmax_agree": agree, "n": int(ref.shape[0]),
+            "min_margin_all": float(margin.min()),
+            "max_margin_of_flipped": float(margin[flipped].max()) if flipped.any() else 0.0}
+
+
+@pytest.fixture
+def math_mode(request):
+    from applecider_amd import hipops as H
+    H.set_math(request.param)
+    yield request.param
+    H.set_math("f32")
+
+
+@pytest.fixture(scope="module")
+def astrominn_case():
+    from applecider_amd.models.astrominn import AstroMiNN
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    sd = closed_form_sd(AstroMiNN(cfg_default()))
+    b = make_batch(256, seed=1)
+    with torch.no_grad():
+        ref = O.astrominn_forward(sd, T(b["metadata"]), T(b["image"]))
+    return sd, b, ref
+
+
+@pytest.fixture(scope="module")
+def fused_case():
+    from applecider_amd.config import default_config
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    sd = closed_form_sd(AppleCider(dict(FUSED_CFG)))
+    b = make_batch(512, seed=2)
+    host = [T(b[k]) for k in ("photometry", "pad_mask", "metadata", "image", "spectra")]
+    ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": "avg",
+            "kernel_sizes_per_stage": default_config()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    with torch.no_grad():
+        ref = O.applecider_forward(sd, *host, ocfg)
+    return sd, host, ref
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3", "bf16"], indirect=True)
+def test_astrominn_b256_vs_cpu_oracle(dev, math_mode, astrominn_case):
+    """BASELINE configs[1]: image + metadata two-branch model, B = 256, logits vs the CPU path."""
+    from applecider_amd.models.astrominn import AstroMiNN
+    sd, b, ref = astrominn_case
+    m = AstroMiNN(cfg_default())
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        logits = m((T(b["metadata"]).to(dev), T(b["image"]).to(dev), None))
+    rec = _compare(logits, ref)
+    _report(f"configs[1] AstroMiNN B=256 / {math_mode}", rec)
+    if math_mode in ("f32", "bf16x3"):
+        assert rec["max_rel_err"] <= QUALIFIED_TOL, rec
+        assert rec["argmax_agree"] == rec["n"], rec
+    else:
+        assert rec["max_rel_err"] <= BF16_TOL, rec
+        # labels may flip only where the oracle's own top-2 logits are closer than the mode's error
+        assert rec["max_margin_of_flipped"] <= 2 * rec["max_rel_err"], rec
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3", "bf16"], indirect=True)
+def test_fused_b512_vs_cpu_oracle(dev, math_mode, fused_case):
+    """BASELINE configs[2]: full 4-modality model, B = 512 (the benchmark batch), forward logits vs
+    the CPU path; the encoders run on their three HIP streams as in bench.py."""
+    from applecider_amd.models.applecider import AppleCider
+    sd, host, ref = fused_case
+    m = AppleCider(dict(FUSED_CFG))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        logits = m(*[t.to(dev) for t in host])
+    rec = _compare(logits, ref)
+    _report(f"configs[2] fused B=512 / {math_mode}", rec)
+    if math_mode in ("f32", "bf16x3"):
+        assert rec["max_rel_err"] <= QUALIFIED_TOL, rec
+        assert rec["argmax_agree"] == rec["n"], rec
+    else:
+        assert rec["max_rel_err"] <= BF16_TOL, rec
+        assert rec["max_margin_of_flipped"] <= 2 * rec["max_rel_err"], rec
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(0, 300, 200, 1000), (1, 257, 192, 520), (2, 384, 260, 4100)])
+def test_gemm_bf16x3_accuracy(dev, mode, M, N, K):
+    """One split-bf16 product against an fp64 reference: ~2^-16 relative per product, two orders
+    tighter than a bf16 product and within 4x of the exact fp32 kernel."""
+    from applecider_amd import _lib, hipops as H
+    g = torch.Generator().manual_seed(17 + mode)
+    a = torch.randn((K, M) if mode == 2 else (M, K), generator=g)
+    bm = torch.randn((N, K) if mode == 0 else (K, N), generator=g)
+    A64 = (a.double().t() if mode == 2 else a.double())
+    B64 = (bm.double().t() if mode == 0 else bm.double())
+    want = A64 @ B64
+    errs = {}
+    for name, math in (("f32", _lib.MATH_F32), ("bf16x3", _lib.MATH_BF16X3), ("bf16", _lib.MATH_BF16)):
+        ad, bd = a.to(dev), bm.to(dev)
+        c = torch.empty(M, N, device=dev)
+        H.gemm(mode, M, N, K, H.mat(H._p(ad), ad.shape[1]), H.mat(H._p(bd), bd.shape[1]), H.mat(H._p(c), N),
+               math=math)
+        errs[name] = float((c.cpu().double() - want).abs().max() / want.abs().max())
+    _report(f"gemm mode {mode} {M}x{N}x{K}", errs)
+    assert errs["bf16x3"] <= 2e-5, errs
+    assert errs["bf16x3"] <= 0.02 * errs["bf16"], errs
+    assert errs["f32"] <= 2e-5, errs
+
+
+def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
+    """Exact-integer operands (every value a bf16 number): the split product must be exact, with an
+    asymmetric B so that a transposed fragment map cannot pass; plus bias/GELU epilogue and split-K."""
+    from applecider_amd import _lib, hipops as H
+    M, N, K = 192, 160, 96
+    a = torch.arange(M * K, dtype=torch.float32).reshape(M, K).remainder(7) - 3
+    b = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 3).remainder(11) - 5
+    bias = torch.arange(N, dtype=torch.float32) * 0.25
+    want = a @ b.t()
+    ad, bd, biasd = a.to(dev), b.to(dev), bias.to(dev)
+    c = torch.empty(M, N, device=dev)
+    H.gemm(0, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c), N), math=_lib.MATH_BF16X3)
+    assert torch.equal(c.cpu(), want)
+    H.gemm(0, M, N, K, H.mat(H._p(ad), K), H.mat(H._p(bd), K), H.mat(H._p(c), N), bias=biasd,
+           act=_lib.ACT_GELU, math=_lib.MATH_BF16X3)
+    ref = torch.nn.functional.gelu(want + bias)
+    assert (c.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    # TN with split-K atomics: dW = g^T x
+    at, bt = a.t().contiguous().to(dev), b.t().contiguous().to(dev)   # [K, M], [K, N]
+    c2 = torch.zeros(M, N, device=dev)
+    H.gemm(2, M, N, K, H.mat(H._p(at), M), H.mat(H._p(bt), N), H.mat(H._p(c2), N), accumulate=2, split_k=3,
+           math=_lib.MATH_BF16X3)
+    assert torch.equal(c2.cpu(), want)
