@@ -109,6 +109,11 @@ SIGNATURES = {
     "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
     "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
+    "ac_mha_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
+    "ac_split_bf16": [_P, _P, _P, _I64, _P],
+    "ac_transpose_split_bf16": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
+    "ac_pad_rows_split": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_moe_top2_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_moe_top2_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_l2norm_fwd": [_P, _P, _P, _I64, _I32, _P],

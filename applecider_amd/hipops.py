@@ -1498,6 +1498,9 @@ def embed(x8, W8, bias, tw, tb, cls):
     return _Embed.apply(x8, W8, bias, tw, tb, cls)
 
 
+_MHA_MFMA = True   # tests switch the matrix-core attention kernels off to compare with the scalar ones
+
+
 class _MHA(Function):
     @staticmethod
     def forward(ctx, qkv, pad_u8, H, p_drop, seed):
@@ -1507,10 +1510,19 @@ class _MHA(Function):
         Dh = D // H
         out = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
-        _lib.check(_lib_().ac_mha_fwd(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
-                                      seed, _stream()), "ac_mha_fwd")
+        # matrix-core kernels (ac_attn.hip) in the bf16 / split-bf16 modes; the exact fp32 mode and
+        # shapes they do not cover (d_head != 16, T > 288) use the scalar fp32 kernels
+        mfma = _MHA_MFMA and _MATH != _lib.MATH_F32 and Dh == 16 and T <= 288
+        split = 1 if _MATH == _lib.MATH_BF16X3 else 0
+        if mfma:
+            _lib.check(_lib_().ac_mha_fwd_mfma(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
+                                               seed, split, _stream()), "ac_mha_fwd_mfma")
+        else:
+            _lib.check(_lib_().ac_mha_fwd(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
+                                          seed, _stream()), "ac_mha_fwd")
         ctx.save_for_backward(qkv, pad_u8, out, lse)
         ctx.cfg = (B, T, H, Dh, p_drop, seed)
+        ctx.mfma, ctx.split = mfma, split
         return out
 
     @staticmethod
@@ -1519,8 +1531,13 @@ class _MHA(Function):
         B, T, H, Dh, p_drop, seed = ctx.cfg
         dout = _chk(dout, "dout")
         dqkv = torch.empty_like(qkv)
-        _lib.check(_lib_().ac_mha_bwd(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
-                                      T, H, Dh, p_drop, seed, _stream()), "ac_mha_bwd")
+        if ctx.mfma:
+            _lib.check(_lib_().ac_mha_bwd_mfma(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
+                                               T, H, Dh, p_drop, seed, ctx.split, _stream()),
+                       "ac_mha_bwd_mfma")
+        else:
+            _lib.check(_lib_().ac_mha_bwd(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
+                                          T, H, Dh, p_drop, seed, _stream()), "ac_mha_bwd")
         return dqkv, None, None, None, None
 
 

@@ -136,6 +136,14 @@ int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
 /* y = bf16(x) elementwise (round to nearest even); y is a uint16 buffer. */
 int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream);
 /* y[c, r] = bf16(x[r, c]) : the k-contiguous bf16 copy of an operand stored row-contiguous. */
+/* Split-bf16 planes for math mode bf16x3: hi = bf16(x), lo = bf16(x - hi) (round to nearest even).
+ * ac_split_bf16: elementwise; ac_transpose_split_bf16: [rows, cols] -> two [cols, rows] planes;
+ * ac_pad_rows_split: the zero-padded [B, Lp, C] planes of x [B, L, C] (C % 8 == 0). */
+int ac_split_bf16(const float *x, void *hi, void *lo, int64_t n, ac_stream_t stream);
+int ac_transpose_split_bf16(const float *x, int64_t ldx, void *hi, void *lo, int64_t ldy, int64_t rows,
+                            int32_t cols, ac_stream_t stream);
+int ac_pad_rows_split(const float *x, void *hi, void *lo, int32_t B, int32_t L, int32_t C, int32_t pad_lo,
+                      int32_t Lp, ac_stream_t stream);
 int ac_transpose_cast_bf16(const float *x, int64_t ldx, void *y, int64_t ldy, int64_t rows,
                            int32_t cols, ac_stream_t stream);
 /* Batched form over a flat parameter buffer: segs (device, 4 x int64 per segment) =
@@ -318,6 +326,18 @@ int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int
 int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
                const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
                float p_drop, uint64_t seed, ac_stream_t stream);
+
+/* The same attention on the matrix cores (d_head = 16, T <= 288; v_mfma_f32_32x32x16_bf16 tiles for
+ * Q K^T, P V and the three backward contractions; same lse / dropout-index contract as above, so the
+ * two forward / backward pairs are interchangeable).  split = 0: bf16 operands (math mode bf16);
+ * split = 1: (hi, lo) bf16 halves, 3 MFMAs per product (math mode bf16x3).  The exact-fp32 mode keeps
+ * ac_mha_fwd / ac_mha_bwd.  Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer
+ * (HyraxBaselineCLS.py:24-31,73-79). */
+int ac_mha_fwd_mfma(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B, int32_t T,
+                    int32_t H, int32_t Dh, float p_drop, uint64_t seed, int32_t split, ac_stream_t stream);
+int ac_mha_bwd_mfma(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
+                    const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
+                    float p_drop, uint64_t seed, int32_t split, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Towers / MoE / fusion head (astrominn.py:264-295; _archive core/model.py:40-67).

@@ -23,6 +23,27 @@ def build(cls, cfg, dev, salt=0):
     return m.to(dev)
 
 
+@pytest.mark.parametrize("tag,dims", [("a", (2, 16, 32)), ("b", (19, 128, 32)), ("c", (288, 128, 5))])
+def test_residual_tower_golden(dev, tag, dims):
+    """A3 (astrominn.py:44-64) on its own against the reference's golden g1: a metadata tower with a
+    skip projection (2 -> 32), the 19-column mega tower, and an expert block (288 -> 5); output, input
+    gradient and two weight gradients."""
+    from applecider_amd.models.astrominn import ResidualTowerBlock
+    g = gold("g1_towers.npz")
+    i, h, o = dims
+    m = ResidualTowerBlock(i, h, o)
+    m.load_state_dict(closed_form_sd(m))
+    m = m.to(dev).eval()
+    x = T(np.random.default_rng(100 + i).standard_normal((8, i)).astype(np.float32)).to(dev).requires_grad_()
+    y = m(x)
+    assert_close(y, g[f"{tag}.y"], LOGIT_TOL, "y")
+    (dx,) = torch.autograd.grad(y, x, 2.0 * y.detach(), retain_graph=True)      # d/dx of sum(y^2)
+    assert_close(dx, g[f"{tag}.dx"], GRAD_TOL, "dx")
+    gw = torch.autograd.grad(y, [m.start_path[0].weight, m.activation[2].weight], 2.0 * y.detach())
+    assert_close(gw[0], g[f"{tag}.dw_start"], GRAD_TOL, "dw start_path.0")
+    assert_close(gw[1], g[f"{tag}.dw_act"], GRAD_TOL, "dw activation.2")
+
+
 def test_astrominn_golden(dev):
     from applecider_amd.models.astrominn import AstroMiNN
     from applecider_amd.synthetic import make_batch
