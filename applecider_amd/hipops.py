@@ -179,6 +179,60 @@ def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def split16(t: torch.Tensor):
+    """(hi, lo) bf16 planes of an fp32 tensor: hi = bf16(t), lo = bf16(t - hi)  (math mode bf16x3)."""
+    hi = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib_().ac_split_bf16(_p(t), _p(hi), _p(lo), t.numel(), _stream()), "ac_split_bf16")
+    return hi, lo
+
+
+def split16_T(t2d: torch.Tensor):
+    """[R, C] fp32 -> (hi, lo) planes of the transpose [C, R]."""
+    R, Cc = t2d.shape
+    hi = torch.empty(Cc, R, device=t2d.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib_().ac_transpose_split_bf16(_p(t2d), Cc, _p(hi), _p(lo), R, R, Cc, _stream()),
+               "ac_transpose_split_bf16")
+    return hi, lo
+
+
+def split16_w(w):
+    return _cached(w, "s", split16)
+
+
+def split16_wT(w2d):
+    return _cached(w2d, "st", split16_T)
+
+
+def _pad_rows_split(x, B, L, Cn, pad_lo, Lp):
+    hi = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib_().ac_pad_rows_split(_p(x), _p(hi), _p(lo), B, L, Cn, pad_lo, Lp, _stream()),
+               "ac_pad_rows_split")
+    return hi, lo
+
+
+def x3_mode() -> bool:
+    return _MATH == _lib.MATH_BF16X3
+
+
+def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w_planes,
+                   w_row_stride, w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate) -> bool:
+    """Split-bf16 conv through the LDS-resident-window kernel: three passes over (hi, lo) operand
+    planes — hi*hi (+bias), lo*hi, hi*lo — accumulating in the fp32 output.  False when the shape is
+    not covered (nothing has been written then)."""
+    (ah, al), (wh, wl) = a_planes, w_planes
+    if not conv_window(ah, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, wh, w_row_stride,
+                       w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate):
+        return False
+    for a_, w_ in ((al, wh), (ah, wl)):
+        if not conv_window(a_, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w_,
+                           w_row_stride, w_tap_stride, flip, N, c_ptr, ldc, None, True):
+            raise RuntimeError("conv_window_x3: the kernel accepted the first pass only")
+    return True
+
+
 _step_cache: dict = {}
 
 
@@ -1271,8 +1325,15 @@ class _ConvGroup1d(Function):
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
             Lp = L + 2 * Pmax
             xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
+            # split-bf16 mode: the conv products run on the LDS-window kernel over (hi, lo) planes of the
+            # padded input and of the taps (3 passes); the fp32 copy stays for the weight-gradient product
+            xplanes = _pad_rows_split(x, B, L, Cin, Pmax, Lp) if (x3_mode() and _CONVWIN and Cin % 8 == 0) else None
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
+                if xplanes is not None and conv_window_x3(
+                        xplanes, Lp * Cin, Cin, 0, off, B, L, Cin, k, split16_w(ws[j]), k * Cin, Cin, False, Cout,
+                        _p(ycat, j * Cout), Ncat, bs[j], False):
+                    continue
                 wop = cast16_w(ws[j]) if b16 else ws[j]
                 if cat16:
                     if conv_window(xpad, Lp * Cin, Cin, 0, off, B, L, Cin, k, wop, k * Cin, Cin, False,
@@ -1382,7 +1443,8 @@ class _ConvGroup1d(Function):
 
         grads = []
         dx = None
-        if need_dx and dypad is None:
+        x3win = bool(need_dx and not b16 and x3_mode() and _CONVWIN and Ncat % 8 == 0 and Cout % 8 == 0)
+        if need_dx and dypad is None and not x3win:
             # one zero-padded (bf16 in bf16 mode) copy of d(ycat) serves the input-gradient products
             # (as the window / gathered operand) and the weight-gradient products (rows Pmax..Pmax+L)
             dypad = (_pad_rows16 if b16 else _pad_rows)(dycat, B, L, Ncat, Pmax, Lpd)
@@ -1410,10 +1472,15 @@ class _ConvGroup1d(Function):
         else:
             if need_dx:
                 dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
+            dyplanes = _pad_rows_split(dycat, B, L, Ncat, Pmax, Lpd) if x3win else None
             for j, k in enumerate(ksizes):
                 p = k // 2
                 off = Pmax - p
-                if ctx.needs_input_grad[0]:
+                if ctx.needs_input_grad[0] and dyplanes is not None and conv_window_x3(
+                        dyplanes, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, split16_wT(ctx.params[0][j]),
+                        Cout, Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):
+                    pass
+                elif ctx.needs_input_grad[0]:
                     goff = _table(("cg_dx", Ncat, Cout, j, k, Pmax),
                                   lambda j=j, k=k, p=p: [(Pmax + p - t) * Ncat + j * Cout + cb * 32
                                                          for t in range(k)
@@ -1434,6 +1501,8 @@ class _ConvGroup1d(Function):
                              mat(_p(wT), Cout, goff=goff_b), mat(_p(dx), Cin),
                              accumulate=0 if j == 0 else 1, math=mth)
                     elif not b16:
+                        if dypad is None:
+                            dypad = _pad_rows(dycat, B, L, Ncat, Pmax, Lpd)
                         gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
