@@ -57,6 +57,16 @@ class ConvWinDesc(C.Structure):
                 ("c16", C.c_void_p), ("ldc16", C.c_int64)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("dy_batch_stride", C.c_int64), ("dy_row_stride", C.c_int64),
+                ("dy_row_base", C.c_int32), ("dy_col_off", C.c_int32),
+                ("x", C.c_void_p), ("x_batch_stride", C.c_int64), ("x_row_stride", C.c_int64),
+                ("x_row_base", C.c_int32), ("x_rows", C.c_int32),
+                ("B", C.c_int32), ("L", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32), ("k", C.c_int32),
+                ("split_k", C.c_int32), ("dw", C.c_void_p), ("ldw", C.c_int64),
+                ("dy_lo_off", C.c_int64), ("x_lo_off", C.c_int64)]
+
+
 class AdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -109,6 +119,7 @@ SIGNATURES = {
     "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
     "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_conv1d_wgrad_bf16": [C.POINTER(WgradDesc), _P],
     "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
     "ac_mha_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
     "ac_split_bf16": [_P, _P, _P, _I64, _P],

@@ -1,0 +1,223 @@
+// Weight gradient of a 'same' Conv1d on the bf16 matrix cores with the input window resident in LDS
+// (gfx950).  dW[co, t, ci] = sum_{b, l} dy[b, l, co] * xpad[b, l + t + off, ci]
+// (SpectraNetBlock conv bank, src/applecider/models/spectranet.py:18-20,25; torch's conv1d backward).
+//
+// As a plain TN product (M = Cout, N = k*Cin, K = B*L) the B operand of tap t is the padded input
+// shifted by t rows, so a 128 x 256 output tile (4 taps x 64 channels) streams four shifted copies of
+// the same rows: 3.8x more fabric traffic than the data holds (profiles/r01_pmc_hbm_traffic.json).
+// Here a 512-thread workgroup owns 128 output channels x 8 TAPS x 64 input channels and, per K step
+// of 64 positions, loads ONE dy tile [64 x 128] and ONE input window [(64 + 7) x 64]; the B fragments
+// of tap t are transposed reads (ds_read_b64_tr_b16) of the window at a row offset of t.  Operand bytes
+// per FLOP drop 4x against the 128 x 256 tile, which moves the product from the L2-feed bound
+// (~700 TF) towards the MFMA bound.
+//   waves   8 = 2 (64 output channels each) x 4 (2 taps each); 8 accumulator tiles of 32x32 per wave
+//   LDS     dy image [64][128 + 32], window image [72][64 + 32] bf16, two stages
+//   K split over workgroups (blockIdx.y), fp32 atomics into dW (two 128-byte segments per instruction)
+// SPLIT: operands are (hi, lo) bf16 planes (math mode bf16x3): 3 MFMAs per product, images doubled.
+#include "ac_common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_TAPS = 8, WG_KP = 64, WG_CO = 128, WG_CI = 64;
+constexpr int A_PITCH = WG_CO + 32, B_PITCH = WG_CI + 32, B_ROWS = WG_KP + WG_TAPS;   // 72 rows
+constexpr int A_IMG = WG_KP * A_PITCH, B_IMG = B_ROWS * B_PITCH;
+
+struct WgradParams {
+    ac_wgrad_desc d;
+    int co_tiles, ci_tiles, tap_chunks, steps_total, steps_per_split;
+};
+
+// 8 consecutive k (positions) of column `col` of an [k][cols] image: two transposed 4x16 block reads
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_t(const unsigned short *img, int colbase, int s, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int k0 = 16 * s + 8 * (g >> 1);
+    const unsigned short *a0 = img + (k0 + q) * PITCH + colbase + 16 * (g & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
+    const ac_wgrad_desc &d = p.d;
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int STAGE = NPL * (A_IMG + B_IMG);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // tile order: tap chunk fastest (neighbouring chunks share dy tiles and overlapping windows in L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tc = wg % p.tap_chunks;
+    const int cit = (wg / p.tap_chunks) % p.ci_tiles;
+    const int cot = wg / (p.tap_chunks * p.ci_tiles);
+    const int t0 = tc * WG_TAPS;
+
+    const int s_begin = blockIdx.y * p.steps_per_split;
+    int s_end = s_begin + p.steps_per_split;
+    if (s_end > p.steps_total) s_end = p.steps_total;
+    if (s_begin >= s_end) return;
+
+    const unsigned short *dy = (const unsigned short *)d.dy, *x = (const unsigned short *)d.x;
+    // loader roles: dy tile 64 rows x 16 chunks = 1024 chunks (2 per thread); window 72 rows x 8 chunks
+    const int ar = t >> 4, ac = t & 15;            // + 32 rows for the second chunk
+    const int br = t >> 3, bc = t & 7;             // rows 0..63 ; second chunk: rows 64..71 (t < 64)
+    const int steps_per_seq = d.L / WG_KP;
+
+    auto gload_step = [&](int step, u32x4 (&ra)[2 * NPL], u32x4 (&rb)[2 * NPL]) {
+        const int b = step / steps_per_seq, l0 = (step - b * steps_per_seq) * WG_KP;
+        const unsigned short *ap = dy + (int64_t)b * d.dy_batch_stride +
+                                   (int64_t)(d.dy_row_base + l0 + ar) * d.dy_row_stride + d.dy_col_off +
+                                   cot * WG_CO + ac * 8;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            ra[2 * pl] = ac_gload<u32x4>(ap + pl * d.dy_lo_off);
+            ra[2 * pl + 1] = ac_gload<u32x4>(ap + pl * d.dy_lo_off + 32 * d.dy_row_stride);
+        }
+        int row0 = d.x_row_base + l0 + t0 + br;
+        int row1 = d.x_row_base + l0 + t0 + 64 + ((t >> 3) & 7);   // rows 64..71 (stored by threads 0..63 only)
+        row0 = row0 < d.x_rows ? row0 : d.x_rows - 1;
+        row1 = row1 < d.x_rows ? row1 : d.x_rows - 1;
+        const unsigned short *bp = x + (int64_t)b * d.x_batch_stride + cit * WG_CI + bc * 8;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            rb[2 * pl] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)row0 * d.x_row_stride);
+            rb[2 * pl + 1] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)row1 * d.x_row_stride);
+        }
+    };
+    auto lds_store = [&](unsigned short *stage, const u32x4 (&ra)[2 * NPL], const u32x4 (&rb)[2 * NPL]) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            unsigned short *ai = stage + pl * A_IMG, *bi = stage + NPL * A_IMG + pl * B_IMG;
+            *(u32x4 *)(ai + ar * A_PITCH + ac * 8) = ra[2 * pl];
+            *(u32x4 *)(ai + (ar + 32) * A_PITCH + ac * 8) = ra[2 * pl + 1];
+            *(u32x4 *)(bi + br * B_PITCH + bc * 8) = rb[2 * pl];
+            if (t < 64) *(u32x4 *)(bi + (64 + (t >> 3)) * B_PITCH + bc * 8) = rb[2 * pl + 1];
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](const unsigned short *stage) {
+        const unsigned short *ah = stage, *al = stage + A_IMG;
+        const unsigned short *bh = stage + NPL * A_IMG, *bl = bh + B_IMG;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a_h[2], a_l[2], b_h[4], b_l[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a_h[i] = frag_t<A_PITCH>(ah, wm * 64 + 32 * i, s, lane);
+                if (SPLIT) a_l[i] = frag_t<A_PITCH>(al, wm * 64 + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = 2 * wn + (j >> 1), ch = 32 * (j & 1);
+                b_h[j] = frag_t<B_PITCH>(bh + tap * B_PITCH, ch, s, lane);
+                if (SPLIT) b_l[j] = frag_t<B_PITCH>(bl + tap * B_PITCH, ch, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l[i], b_h[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_l[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_h[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    unsigned short *S0 = smw, *S1 = smw + STAGE;
+    u32x4 ra[2 * NPL], rb[2 * NPL];
+    gload_step(s_begin, ra, rb);
+    lds_store(S0, ra, rb);
+    __syncthreads();
+    int cur = 0;
+    for (int step = s_begin; step < s_end; ++step) {
+        const bool more = step + 1 < s_end;
+        if (more) gload_step(step + 1, ra, rb);
+        compute(cur ? S1 : S0);
+        if (more) lds_store(cur ? S0 : S1, ra, rb);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // dW[co, t, ci] += acc (fp32 atomics; lanes 0..31 of a register cover 32 consecutive ci)
+    float *dw = d.dw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tap = t0 + 2 * wn + (j >> 1);
+        if (tap >= d.k) continue;
+        const int ci = cit * WG_CI + 32 * (j & 1) + li;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = cot * WG_CO + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                atomicAdd(dw + (int64_t)co * d.ldw + (int64_t)tap * d.Cin + ci, acc[i][j][e]);
+            }
+    }
+}
+
+template <bool SPLIT>
+int launch_wgrad(WgradParams &p, hipStream_t stream) {
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr size_t LDS = (size_t)2 * NPL * (A_IMG + B_IMG) * sizeof(short);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (attr != hipSuccess) return -(int)attr - 2000;
+    const ac_wgrad_desc &d = p.d;
+    dim3 grid(p.co_tiles * p.ci_tiles * p.tap_chunks, (p.steps_total + p.steps_per_split - 1) / p.steps_per_split);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT>), grid, dim3(512), LDS, stream, p);
+    AC_CHECK_LAUNCH();
+    (void)d;
+    return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream) {
+    if (!dp) return AC_EINVAL;
+    WgradParams p;
+    p.d = *dp;
+    const ac_wgrad_desc &d = p.d;
+    if (!d.dy || !d.x || !d.dw || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.Cout <= 0 || d.Cin <= 0) return AC_EINVAL;
+    // shapes outside the tile grid go back to the caller's generic TN product
+    if ((d.L % WG_KP) || (d.Cout % WG_CO) || (d.Cin % WG_CI)) return AC_EINVAL;
+    if (!ac_aligned16(d.dy) || !ac_aligned16(d.x) || (d.dy_row_stride % 8) || (d.dy_batch_stride % 8) ||
+        (d.dy_col_off % 8) || (d.x_row_stride % 8) || (d.x_batch_stride % 8) || (d.dy_lo_off % 8) ||
+        (d.x_lo_off % 8))
+        return AC_EALIGN;
+    if (d.x_rows <= 0 || d.ldw < (int64_t)d.k * d.Cin) return AC_EINVAL;
+    p.co_tiles = d.Cout / WG_CO;
+    p.ci_tiles = d.Cin / WG_CI;
+    p.tap_chunks = (d.k + WG_TAPS - 1) / WG_TAPS;
+    p.steps_total = d.B * (d.L / WG_KP);
+    int split = d.split_k > 0 ? d.split_k : 1;
+    if (split > p.steps_total) split = p.steps_total;
+    p.steps_per_split = (p.steps_total + split - 1) / split;
+    const bool sp = d.dy_lo_off != 0 || d.x_lo_off != 0;
+    if (sp && (d.dy_lo_off == 0 || d.x_lo_off == 0)) return AC_EINVAL;
+    return sp ? launch_wgrad<true>(p, (hipStream_t)stream) : launch_wgrad<false>(p, (hipStream_t)stream);
+}

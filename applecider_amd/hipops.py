@@ -410,6 +410,35 @@ def conv_window(a16, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw
     return True
 
 
+_WGRAD_WIN = True   # tests switch the LDS-window weight-gradient kernel off to compare with the TN product
+
+
+def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_off, x, x_lo, x_batch_stride,
+               x_row_stride, x_row_base, x_rows, B, L, Cout, Cin, k, dw) -> bool:
+    """dw[Cout, k*Cin] += conv weight gradient through the LDS-window kernel (ac_conv1d_wgrad_bf16).
+    dy / x are bf16 tensors (dy_lo / x_lo: the lo planes in split-bf16 mode, else None).  False when
+    the shape is not covered (the caller then runs the generic TN product)."""
+    if not _WGRAD_WIN or k < 7 or L % 64 or Cout % 128 or Cin % 64:
+        return False
+    d = _lib.WgradDesc()
+    d.dy, d.dy_batch_stride, d.dy_row_stride = _p(dy), dy_batch_stride, dy_row_stride
+    d.dy_row_base, d.dy_col_off = dy_row_base, dy_col_off
+    d.x, d.x_batch_stride, d.x_row_stride = _p(x), x_batch_stride, x_row_stride
+    d.x_row_base, d.x_rows = x_row_base, x_rows
+    d.B, d.L, d.Cout, d.Cin, d.k = B, L, Cout, Cin, k
+    tiles = (Cout // 128) * (Cin // 64) * (-(-k // 8))
+    steps = B * (L // 64)
+    d.split_k = max(1, min(steps // 16, -(-512 // tiles)))
+    d.dw, d.ldw = _p(dw), k * Cin
+    d.dy_lo_off = (dy_lo.data_ptr() - dy.data_ptr()) // 2 if dy_lo is not None else 0
+    d.x_lo_off = (x_lo.data_ptr() - x.data_ptr()) // 2 if x_lo is not None else 0
+    rc = _lib_().ac_conv1d_wgrad_bf16(C.byref(d), _stream())
+    if rc == _lib.AC_EINVAL:
+        return False
+    _lib.check(rc, "ac_conv1d_wgrad_bf16")
+    return True
+
+
 def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     """Split-K factor of a weight-gradient product (measured, tools/bench_split.py): long reductions
     get >= 64 K tiles per workgroup and up to 4 workgroups per CU; skinny outputs that cannot fill
@@ -1351,6 +1380,7 @@ class _ConvGroup1d(Function):
                      mat(_p(wop), k * Cin),
                      mat(_p(ycat, j * Cout), Ncat), bias=bs[j], math=mth)
             ctx.Lp = Lp
+            ctx.xplanes = xplanes
         ctx.fused_ln = ln_gamma is not None
         ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
         if ctx.fused_ln:
@@ -1510,10 +1540,25 @@ class _ConvGroup1d(Function):
                 wsink = _sink(ctx.params[0][j])
                 dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev,
                                                                   dtype=torch.float32)
-                tile_, split_ = _tn_plan(Cout, k * Cin, B * L) if b16 else (0, _split_for(Cout, k * Cin, B * L))
-                gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),
-                     mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
-                     mat(_p(dw), k * Cin), accumulate=2, split_k=split_, tile=tile_, math=mth)
+                done = False
+                if b16:
+                    # LDS-window weight-gradient kernel: 8 taps x 64 channels share one input window
+                    if dypad is not None and need_dx:
+                        done = conv_wgrad(dypad, None, Lpd * Ncat, Ncat, Pmax, j * Cout, xpad, None, Lp * Cin,
+                                          Cin, off, Lp, B, L, Cout, Cin, k, dw)
+                    else:
+                        done = conv_wgrad(dyop, None, L * Ncat, Ncat, 0, j * Cout, xpad, None, Lp * Cin, Cin,
+                                          off, Lp, B, L, Cout, Cin, k, dw)
+                elif x3_mode() and getattr(ctx, "xplanes", None) is not None and Ncat % 8 == 0:
+                    if dyplanes is None:
+                        dyplanes = _pad_rows_split(dycat, B, L, Ncat, Pmax, Lpd)
+                    done = conv_wgrad(dyplanes[0], dyplanes[1], Lpd * Ncat, Ncat, Pmax, j * Cout,
+                                      ctx.xplanes[0], ctx.xplanes[1], Lp * Cin, Cin, off, Lp, B, L, Cout, Cin, k, dw)
+                if not done:
+                    tile_, split_ = _tn_plan(Cout, k * Cin, B * L) if b16 else (0, _split_for(Cout, k * Cin, B * L))
+                    gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),
+                         mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
+                         mat(_p(dw), k * Cin), accumulate=2, split_k=split_, tile=tile_, math=mth)
                 if wsink is not None:
                     dw = None
                     _grad_written(ctx.params[0][j])

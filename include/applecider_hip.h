@@ -327,6 +327,28 @@ int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
                const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
                float p_drop, uint64_t seed, ac_stream_t stream);
 
+/* Weight gradient of a 'same' Conv1d with the input window resident in LDS (ac_wgrad.hip):
+ *   dw[co, t*Cin + ci] += sum_{b, l} dy[b, dy_row_base + l, dy_col_off + co] * x[b, x_row_base + l + t, ci]
+ * dy and x are bf16 ([B, rows, row_stride] views, strides / offsets in elements, multiples of 8);
+ * L % 64 == 0, Cout % 128 == 0, Cin % 64 == 0 (AC_EINVAL otherwise: use the generic TN ac_gemm).
+ * dy_lo_off / x_lo_off != 0: element offsets from the hi plane to the lo plane of split-bf16 operands
+ * (math mode bf16x3).  dw is fp32 [Cout, ldw], accumulated with atomics (zero or pre-filled by caller).
+ * Replaces the weight-gradient half of torch's conv1d backward for spectranet.py:18-20. */
+typedef struct ac_wgrad_desc {
+    const void *dy;
+    int64_t dy_batch_stride, dy_row_stride;
+    int32_t dy_row_base, dy_col_off;
+    const void *x;
+    int64_t x_batch_stride, x_row_stride;
+    int32_t x_row_base, x_rows;   /* x_rows: rows per batch of the padded input (loads are clamped) */
+    int32_t B, L, Cout, Cin, k;
+    int32_t split_k;              /* workgroups along the B*L reduction */
+    float *dw;
+    int64_t ldw;
+    int64_t dy_lo_off, x_lo_off;
+} ac_wgrad_desc;
+int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *d, ac_stream_t stream);
+
 /* The same attention on the matrix cores (d_head = 16, T <= 288; v_mfma_f32_32x32x16_bf16 tiles for
  * Q K^T, P V and the three backward contractions; same lse / dropout-index contract as above, so the
  * two forward / backward pairs are interchangeable).  split = 0: bf16 operands (math mode bf16);
