@@ -184,18 +184,27 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
-                const unsigned w = (kb * 32 + 8 * g < T) ? *(const unsigned *)(vm8 + key0) : 0u;
+                if (kb * 32 + 8 * g < T) {   // wave-uniform: key groups past T cost nothing
+                    const unsigned w = *(const unsigned *)(vm8 + key0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sv[4 * g + e] = ((w >> (8 * e)) & 0xFFu) ? S[4 * g + e] : -INFINITY;
-                    bm = fmaxf(bm, sv[4 * g + e]);
+                    for (int e = 0; e < 4; ++e) {
+                        sv[4 * g + e] = ((w >> (8 * e)) & 0xFFu) ? S[4 * g + e] : -INFINITY;
+                        bm = fmaxf(bm, sv[4 * g + e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[4 * g + e] = -INFINITY;
                 }
             }
             const float mn = fmaxf(m, bm);
             const float mref = (mn == -INFINITY) ? 0.f : mn;
             float acc = l * __expf(m - mref);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc += __expf(sv[e] - mref);
+            for (int g = 0; g < 4; ++g)
+                if (kb * 32 + 8 * g < T) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += __expf(sv[4 * g + e] - mref);
+                }
             l = acc;
             m = mn;
         }
@@ -218,12 +227,17 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
-                const unsigned w = (kb * 32 + 8 * g < T) ? *(const unsigned *)(vm8 + key0) : 0u;
+                if (kb * 32 + 8 * g < T) {
+                    const unsigned w = *(const unsigned *)(vm8 + key0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
-                    if (DROP) p = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? p * inv_keep : 0.f;
-                    pv[4 * g + e] = p;
+                    for (int e = 0; e < 4; ++e) {
+                        float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
+                        if (DROP) p = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? p * inv_keep : 0.f;
+                        pv[4 * g + e] = p;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[4 * g + e] = 0.f;
                 }
             }
 #pragma unroll
@@ -325,13 +339,18 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
-                const unsigned w = (kb * 32 + 8 * g < T) ? *(const unsigned *)(vm8 + key0) : 0u;
+                if (kb * 32 + 8 * g < T) {
+                    const unsigned w = *(const unsigned *)(vm8 + key0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
-                    float ks = 1.f;
-                    if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
-                    ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
+                        float ks = 1.f;
+                        if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
+                        ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds[4 * g + e] = 0.f;
                 }
             }
 #pragma unroll

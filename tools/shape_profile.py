@@ -13,9 +13,10 @@ import bench
 
 dev = torch.device('cuda')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-H.set_math("bf16")
+H.set_math(sys.argv[2] if len(sys.argv) > 2 else "bf16")
 torch.manual_seed(0)
 net = AppleCider(dict(bench.FUSION_CFG)).to(dev).train()
+net.branch_streams = False   # one stream: a launch's HIP-event bracket then times that launch alone
 net.optimizer.prepare()
 b = make_batch(B, seed=2)
 batch = tuple(torch.from_numpy(b[k]).to(dev) for k in
@@ -23,7 +24,18 @@ batch = tuple(torch.from_numpy(b[k]).to(dev) for k in
 
 recs = {}
 on = [False]
-og, ow = H.gemm, H.conv_window
+og, ow, owg = H.gemm, H.conv_window, H.conv_wgrad
+
+
+def twg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw):
+    if not on[0]:
+        return owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); ok = owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw); e.record()
+    if ok:
+        recs.setdefault(("WGR", Cout, k * Cin, Bn * L, "-", 1), []).append((s, e, 2.0 * Bn * L * Cout * k * Cin))
+    return ok
+
 
 
 def tg(mode, M, N, K, a, b, c, **kw):
@@ -46,7 +58,7 @@ def tw(a16, abs_, ars, aco, rb, Bn, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc
     return ok
 
 
-H.gemm, H.conv_window = tg, tw
+H.gemm, H.conv_window, H.conv_wgrad = tg, tw, twg
 for i in range(3):
     on[0] = i == 2
     loss = net.train_step(batch)["loss"]
