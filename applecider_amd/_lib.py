@@ -54,7 +54,7 @@ class ConvWinDesc(C.Structure):
                 ("w", C.c_void_p), ("w_row_stride", C.c_int64), ("w_tap_stride", C.c_int64),
                 ("flip", C.c_int32), ("N", C.c_int32), ("c", C.c_void_p), ("ldc", C.c_int64),
                 ("bias", C.c_void_p), ("accumulate", C.c_int32), ("variant", C.c_int32),
-                ("c16", C.c_void_p), ("ldc16", C.c_int64)]
+                ("c16", C.c_void_p), ("ldc16", C.c_int64), ("a_lo_off", C.c_int64), ("w_lo_off", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -119,6 +119,7 @@ SIGNATURES = {
     "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
     "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_conv1d_window_x3": [C.POINTER(ConvWinDesc), _P],
     "ac_conv1d_wgrad_bf16": [C.POINTER(WgradDesc), _P],
     "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
     "ac_mha_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],

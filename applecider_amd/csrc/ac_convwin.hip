@@ -469,6 +469,201 @@ int launch_ks2(ConvWinParams &p, hipStream_t stream) {
     return AC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 (math mode bf16x3) window conv in ONE launch: A and the taps come as (hi, lo) bf16 planes
+// and every fragment pair is three MFMAs (lo*hi + hi*lo + hi*hi, fp32 accumulate) — against three
+// passes of the kernel above this reads each operand plane once, writes the output once and carries
+// 1.5x more MFMA work per LDS byte.  Two window planes do not fit beside the weight stages for the long
+// taps, so the K loop is cut into CHUNKS: a chunk = 64 input channels x up to TC taps, whose window
+// [(BM + TC - 1) rows x 64 channels x 2 planes] is (re)loaded between chunks while the accumulators
+// stay in registers.  TC is chosen by the host so that the chunk fits the 160 KB LDS (k = 251 at
+// 64 channels: two chunks of 129 + 122 taps).
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWinParams p, int TC) {
+    constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, CC = 64;
+    constexpr int BCH = BN * 8 / NT;          // weight chunks per thread per plane per K tile
+    constexpr int WT = BN * 64;               // one weight plane tile (elements)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short *win_h = reinterpret_cast<unsigned short *>(smem);
+    const ac_convwin_desc &d = p.d;
+    const int Wrows = BM + TC - 1;
+    unsigned short *win_l = win_h + Wrows * CC;
+    unsigned short *bst = win_l + Wrows * CC;  // 2 stages x (hi tile | lo tile)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tn = wg % p.tiles_n;
+    const int tl = (wg / p.tiles_n) % p.tiles_l;
+    const int b = wg / (p.tiles_n * p.tiles_l);
+    const int l0 = tl * BM;
+
+    const unsigned short *aptr = (const unsigned short *)d.a + (int64_t)b * d.a_batch_stride +
+                                 (int64_t)(d.row_base + l0) * d.a_row_stride + d.a_col_off;
+    const unsigned short *wptr = (const unsigned short *)d.w;
+    int64_t wbase[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        int n = tn * BN + (t >> 3) + (NT / 8) * i;
+        n = n < d.N ? n : d.N - 1;
+        wbase[i] = (int64_t)n * d.w_row_stride + 8 * (t & 7);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int cchunks = d.C / CC;
+    for (int cch = 0; cch < cchunks; ++cch) {
+        for (int t0 = 0; t0 < d.k; t0 += TC) {
+            const int tc = (d.k - t0) < TC ? (d.k - t0) : TC;   // taps in this chunk (K tiles: one per tap)
+            __syncthreads();   // every wave is done with the previous chunk's window and weight stages
+            {
+                const int rows = BM + tc - 1;
+                const unsigned short *a = aptr + (int64_t)t0 * d.a_row_stride + cch * CC;
+                for (int idx = t; idx < rows * 8; idx += NT) {
+                    const int r = idx >> 3, cc = idx & 7;
+                    const unsigned short *src = a + (int64_t)r * d.a_row_stride + cc * 8;
+                    *(u32x4 *)(win_h + win_off<64>(r, cc)) = ac_gload<u32x4>(src);
+                    *(u32x4 *)(win_l + win_off<64>(r, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
+                }
+            }
+            auto wload = [&](int kt, u32x4 (&v)[2 * BCH]) {
+                const int tap = t0 + kt;
+                const int64_t ko = (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + cch * CC;
+#pragma unroll
+                for (int i = 0; i < BCH; ++i) {
+                    v[i] = ac_gload<u32x4>(wptr + wbase[i] + ko);
+                    v[BCH + i] = ac_gload<u32x4>(wptr + wbase[i] + ko + d.w_lo_off);
+                }
+            };
+            auto wstore = [&](unsigned short *stage, const u32x4 (&v)[2 * BCH]) {
+                const int c = t & 7;
+#pragma unroll
+                for (int i = 0; i < BCH; ++i) {
+                    const int r = (t >> 3) + (NT / 8) * i;
+                    const int off = r * 64 + ((c ^ ((r >> 1) & 7)) << 3);
+                    *(u32x4 *)(stage + off) = v[i];
+                    *(u32x4 *)(stage + WT + off) = v[BCH + i];
+                }
+            };
+            auto compute = [&](int kt, const unsigned short *bt) {
+                const int r0 = wm * 64 + li + kt, r1 = r0 + 32;
+                const int n0 = wn * 64 + li, n1 = n0 + 32;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int cc = 2 * s + lh;
+                    const int ao0 = win_off<64>(r0, cc), ao1 = win_off<64>(r1, cc);
+                    const int bo0 = n0 * 64 + ((cc ^ ((n0 >> 1) & 7)) << 3), bo1 = n1 * 64 + ((cc ^ ((n1 >> 1) & 7)) << 3);
+                    const bf16x8 a0h = *(const bf16x8 *)(win_h + ao0), a1h = *(const bf16x8 *)(win_h + ao1);
+                    const bf16x8 b0h = *(const bf16x8 *)(bt + bo0), b1h = *(const bf16x8 *)(bt + bo1);
+                    const bf16x8 a0l = *(const bf16x8 *)(win_l + ao0), a1l = *(const bf16x8 *)(win_l + ao1);
+                    const bf16x8 b0l = *(const bf16x8 *)(bt + WT + bo0), b1l = *(const bf16x8 *)(bt + WT + bo1);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+                }
+            };
+            unsigned short *S0 = bst, *S1 = bst + 2 * WT;
+            const int last = tc - 1;
+            u32x4 rb0[2 * BCH], rb1[2 * BCH];
+            wload(0, rb0);
+            wstore(S0, rb0);
+            __syncthreads();  // window + first weight tile visible
+            wload(1 < last ? 1 : last, rb0);
+            for (int kt = 0; kt < tc; kt += 2) {
+                wload(kt + 2 < last ? kt + 2 : last, rb1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kt, S0);
+                wstore(S1, rb0);
+                __syncthreads();
+                if (kt + 1 >= tc) break;
+                wload(kt + 3 < last ? kt + 3 : last, rb0);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kt + 1, S1);
+                wstore(S0, rb1);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (fp32 output only): out[b, l0 + m, n] (+)= acc (+ bias), 16-byte stores through LDS
+    float *cb = d.c + ((int64_t)b * d.L + l0) * d.ldc;
+    float *wbuf = smem + wave * 2048;
+    const int rsub = lane >> 4, c4 = 4 * (lane & 15);
+    const int n = tn * BN + wn * 64 + c4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias && n < d.N) bias4 = *(const f32x4 *)(d.bias + n);
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            wbuf[r * 64 + li] = acc[sa][0][e];
+            wbuf[r * 64 + 32 + li] = acc[sa][1][e];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + rsub;
+            f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
+            if (n < d.N) {
+                const int64_t row = wm * 64 + sa * 32 + r;
+                f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
+                if (d.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN>
+int launch_x3(ConvWinParams &p, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+    const ac_convwin_desc &d = p.d;
+    const size_t stages = (size_t)2 * 2 * BN * 64 * sizeof(short);
+    const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
+    int TC = rows_budget - BM + 1;
+    if (TC < 1) return AC_EINVAL;
+    if (TC > d.k) TC = d.k;
+    const size_t lds = (size_t)(BM + TC - 1) * 64 * 2 * sizeof(short) + stages;
+    if (lds < (size_t)WM * WN * 8192) return AC_EINVAL;   // the epilogue parks 8 KB per wave
+    p.tiles_l = d.L / BM;
+    p.tiles_n = (d.N + BN - 1) / BN;
+    p.cchunks = 8;
+    p.vec_epi = 1;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3_kernel<WM, WN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN>), dim3(d.B * p.tiles_l * p.tiles_n), dim3(NT), lds, stream,
+                       p, TC);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
 template <int C>
 int dispatch(ConvWinParams &p, hipStream_t stream) {
     const ac_convwin_desc &d = p.d;
@@ -491,6 +686,25 @@ int dispatch(ConvWinParams &p, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream_) {
+    if (!dp) return AC_EINVAL;
+    ConvWinParams p;
+    p.d = *dp;
+    const ac_convwin_desc &d = p.d;
+    if (!d.a || !d.w || !d.c || d.c16 || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.N <= 0) return AC_EINVAL;
+    if (d.a_lo_off == 0 || d.w_lo_off == 0) return AC_EINVAL;
+    if (d.C <= 0 || (d.C % 64) || (d.L % 128)) return AC_EINVAL;
+    if (!ac_aligned16(d.a) || !ac_aligned16(d.w) || !ac_aligned16(d.c)) return AC_EALIGN;
+    if ((d.a_row_stride % 8) || (d.a_batch_stride % 8) || (d.a_col_off % 8) || (d.w_row_stride % 8) ||
+        (d.w_tap_stride % 8) || (d.a_lo_off % 8) || (d.w_lo_off % 8) || (d.N % 4) || (d.ldc % 4) ||
+        (d.bias && !ac_aligned16(d.bias)))
+        return AC_EALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool wide = d.N > 64;
+    if (d.L % 256 == 0) return wide ? launch_x3<4, 2>(p, stream) : launch_x3<4, 1>(p, stream);
+    return wide ? launch_x3<2, 2>(p, stream) : launch_x3<2, 1>(p, stream);
+}
 
 extern "C" int ac_conv1d_window_bf16(const ac_convwin_desc *dp, ac_stream_t stream_) {
     if (!dp) return AC_EINVAL;

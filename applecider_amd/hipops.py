@@ -223,6 +223,22 @@ def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, 
     planes — hi*hi (+bias), lo*hi, hi*lo — accumulating in the fp32 output.  False when the shape is
     not covered (nothing has been written then)."""
     (ah, al), (wh, wl) = a_planes, w_planes
+    if _CONVWIN and _CONVWIN_X3_FUSED and Cw % 64 == 0 and L % 128 == 0 and N % 4 == 0:
+        # one launch: both planes of the window in LDS (chunked over channels / taps), 3 MFMAs per pair
+        d = _lib.ConvWinDesc()
+        d.a, d.a_batch_stride, d.a_row_stride = _p(ah), a_batch_stride, a_row_stride
+        d.a_col_off, d.row_base = a_col_off, row_base
+        d.B, d.L, d.C, d.k = B, L, Cw, k
+        d.w, d.w_row_stride, d.w_tap_stride = _p(wh), w_row_stride, w_tap_stride
+        d.flip, d.N, d.c, d.ldc = int(flip), N, c_ptr, ldc
+        d.bias, d.accumulate = _p(bias), int(accumulate)
+        d.a_lo_off = (al.data_ptr() - ah.data_ptr()) // 2
+        d.w_lo_off = (wl.data_ptr() - wh.data_ptr()) // 2
+        rc = _lib_().ac_conv1d_window_x3(C.byref(d), _stream())
+        if rc == 0:
+            return True
+        if rc != _lib.AC_EINVAL:
+            _lib.check(rc, "ac_conv1d_window_x3")
     if not conv_window(ah, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, wh, w_row_stride,
                        w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate):
         return False
@@ -380,6 +396,7 @@ class _View16:
 
     def element_size(self):
         return 2
+_CONVWIN_X3_FUSED = True   # tests: False = three passes of the bf16 window kernel instead of the fused one
 _CONVWIN_VARIANT = 0   # 1: keep N <= 64 products on the 4-wave window kernel (A/B tests)
 
 

@@ -52,6 +52,7 @@ class KernelTimer:
     def __init__(self):
         self.records = {}  # name -> list of (start_event, end_event, work)
         self.enabled = False
+        self._suppress = False   # set while an outer wrapper (the split-bf16 conv) times its inner launches
 
     # records hold (start, end, flops, algorithmic bytes).  Algorithmic bytes = every operand and
     # every output read / written ONCE (unique elements of a Toeplitz / padded view, not the k-fold
@@ -91,7 +92,7 @@ class KernelTimer:
         orig = H.conv_window
 
         def timed(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
-            if not self.enabled:
+            if not self.enabled or self._suppress:
                 return orig(a16, abs_, ars, aco, rb, B, L, Cw, k, w16, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -103,6 +104,46 @@ class KernelTimer:
                 self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw, byts))
             return ok
         H.conv_window = timed
+
+    def wrap_conv_window_x3(self, H):
+        """Split-bf16 conv (one fused launch, or three passes of the bf16 window kernel): one record per
+        PRODUCT with its algorithmic FLOP (2 B L N k C) and bytes (both planes of A and W once, fp32 out)."""
+        orig = H.conv_window_x3
+
+        def timed(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+            if not self.enabled:
+                return orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._suppress = True
+            try:
+                s.record()
+                ok = orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+                e.record()
+            finally:
+                self._suppress = False
+            if ok:
+                byts = 4.0 * B * (L + k - 1) * Cw + 4.0 * N * k * Cw + 4.0 * (2 if acc else 1) * B * L * N
+                self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw, byts))
+            return ok
+        H.conv_window_x3 = timed
+
+    def wrap_conv_wgrad(self, H):
+        orig = H.conv_wgrad
+
+        def timed(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw):
+            if not self.enabled:
+                return orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ok = orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw)
+            e.record()
+            if ok:
+                planes = 2 if dy_lo is not None else 1
+                # algorithmic bytes: dy column block and padded x once (bf16, per plane), dW read+written (atomics)
+                byts = 2.0 * planes * (B * L * Cout + B * xrows * Cin) + 8.0 * Cout * k * Cin
+                self.records.setdefault("conv1d_wgrad", []).append((s, e, 2.0 * B * L * Cout * k * Cin, byts))
+            return ok
+        H.conv_wgrad = timed
 
     def wrap_dwconv(self, H):
         lib = H._lib_()
@@ -190,7 +231,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--math", choices=["bf16", "bf16x3", "f32"], default="bf16",
+    ap.add_argument("--math", choices=["bf16", "bf16x3", "f32"], default="bf16x3",
                     help="matrix-core arithmetic (hipops.set_math): bf16x3 and f32 are the modes qualified "
                          "against the 1e-3 logit parity bar, bf16 is the fast unqualified mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,6 +248,9 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 over gloo "
                          "(a one-GPU box cannot host an RCCL communicator with two ranks)")
+    ap.add_argument("--no-fast-mode", action="store_true",
+                    help="skip the secondary measurement of the unqualified fast mode (plain bf16 MFMA inputs), "
+                         "reported as `fast_mode` beside the qualified headline")
     ap.add_argument("--h2d", action="store_true",
                     help="after the timed region, time the same steps again with every batch staged from "
                          "pinned host memory through PinnedStager and report it as `pcie_inclusive`")
@@ -268,8 +312,10 @@ def main():
         return loss
 
     timer = KernelTimer()
+    timer.wrap_conv_window_x3(H)
     timer.wrap_gemm(H)
     timer.wrap_conv_window(H)
+    timer.wrap_conv_wgrad(H)
     timer.wrap_dwconv(H)
 
     for _ in range(args.warmup):
@@ -352,6 +398,31 @@ def main():
         timer.enabled = False
         model.branch_streams = was_streams
 
+    # Secondary measurement: the fast, unqualified arithmetic (plain bf16 MFMA inputs, bf16 hand-overs)
+    # on the same model / batch / step, timed exactly like the headline.  Never `value`.
+    fast = None
+    if args.math != "bf16" and not args.no_fast_mode:
+        H.set_math("bf16")
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        fast = {"dtype": "bf16", "value": round(world * B * args.steps / el, 2), "unit": "samples/s",
+                "ms_per_step": round(el / args.steps * 1e3, 3), "parity_qualified": False,
+                "note": "bf16 MFMA inputs + bf16-only hand-overs: logits are NOT within 1e-3 of the CPU path "
+                        "(tests/test_gpu_parity_modes.py states and checks its looser bounds)"}
+        H.set_math(args.math)
+
     rccl_ranks = ddp.rccl_ranks()
     if rank != 0:
         if world > 1:
@@ -362,12 +433,14 @@ def main():
     timed_steps, args_steps_saved = args.steps, args.steps
     args.steps = roof_steps   # the per-step figures below refer to the roofline pass
     gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d")}
+    kernel_of = {"conv1d_window": "conv1d_window_x3_kernel" if args.math == "bf16x3" else "conv1d_window_kernel",
+                 "conv1d_wgrad": "conv1d_wgrad_kernel"}
     # dominant kernel = the family with the largest summed launch time; inside it every launch is
     # rated against the roof that bounds ITS shape, and the class that holds more of the family's
     # time is reported as `roofline` (the other class is listed beside it)
     dom_name = max(gemms, key=lambda k: gemms[k]["ms"])
     dom = gemms[dom_name]
-    kname = ("conv1d_window_kernel" if dom_name.startswith("conv1d") else
+    kname = (kernel_of[dom_name] if dom_name in kernel_of else
              f"{dom_name} ({ {'bf16': 'gemm_bf16in_kernel', 'bf16x3': 'gemm_x3_kernel'}.get(args.math, 'gemm_f32_kernel') })")
 
     def rate(cls, bound):
@@ -400,16 +473,19 @@ def main():
     # (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # this same command, FETCH_SIZE doubled for gfx950); None when the kernel is not in that file.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        pmc_file = "r02_pmc_hbm_traffic_%s.json" % args.math
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         want = {"gemm<TN>": "gemm_bf16in_kernelILb1ELi2ELi2EE", "gemm<NT>": "gemm_bf16in_kernelILb0ELi2ELi2EE",
-                "conv1d_window": "conv1d_window_kernel"}.get(dom_name)  # mangled names as rocprofv3 stores them
-        if args.math == "bf16" and want:
+                "conv1d_window": "conv1d_window", "conv1d_wgrad": "conv1d_wgrad_kernel"}.get(dom_name)
+        if args.math == "bf16x3" and dom_name.startswith("gemm"):
+            want = "gemm_x3_kernel"
+        if want:
             for k, v in pmc.items():
                 if want in k:
                     roofline["traffic"] = round(v["per_launch_MB"] * 1e6)
                     roofline["traffic_unit"] = ("bytes per launch, average over ALL launches of this kernel "
                                                 "(fabric-side FETCH+WRITE, PMC)")
-                    roofline["traffic_source"] = ("profiles/r01_pmc_hbm_traffic.json (committed rocprofv3 --pmc "
+                    roofline["traffic_source"] = ("profiles/" + pmc_file + " (committed rocprofv3 --pmc "
                                                   "passes of this command, separate FETCH_SIZE / WRITE_SIZE runs, "
                                                   "FETCH_SIZE doubled for gfx950); NOT measured in this run")
                     break
@@ -440,6 +516,8 @@ def main():
                    "encoder_streams": 3 if model.branch_streams else 1},
         "roofline": roofline,
     }
+    if fast is not None:
+        out["fast_mode"] = fast
     if h2d is not None:
         out["pcie_inclusive"] = h2d
     if other is not None:

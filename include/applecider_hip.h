@@ -179,8 +179,14 @@ typedef struct ac_convwin_desc {
     void *c16;          /* nullable: bf16 output (element (b, l, n) at c16 + (b*L + l)*ldc16 + n);
                            c may then be NULL (bf16-only output, accumulate must be 0) */
     int64_t ldc16;
+    int64_t a_lo_off, w_lo_off; /* ac_conv1d_window_x3 only: element offsets from the hi plane of A / W
+                                   to its lo plane (split-bf16 operands, math mode bf16x3) */
 } ac_convwin_desc;
 int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
+/* The same product on split-bf16 operands in one launch: 3 MFMAs per fragment pair, the K loop cut
+ * into chunks of 64 channels x TC taps whose two window planes fit the LDS (any C % 64 == 0, L % 128
+ * == 0, fp32 output only: c16 must be NULL).  AC_EINVAL: shape not covered. */
+int ac_conv1d_window_x3(const ac_convwin_desc *d, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row-wise LayerNorm over the last dimension (nn.LayerNorm: astrominn.py:25,34,47,52;

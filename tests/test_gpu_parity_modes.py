@@ -197,3 +197,40 @@ def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
     H.gemm(2, M, N, K, H.mat(H._p(at), M), H.mat(H._p(bt), N), H.mat(H._p(c2), N), accumulate=2, split_k=3,
            math=_lib.MATH_BF16X3)
     assert torch.equal(c2.cpu(), want)
+
+
+@pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (2, 128, 128, 64, (3, 15, 61)),
+                                             (1, 256, 256, 128, (7, 13, 31)), (2, 64, 128, 256, (3, 15, 61))])
+def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
+    """The SpectraNetBlock conv bank in split-bf16 mode — forward and input gradient on the window
+    kernel over (hi, lo) planes (fused single launch with chunked windows, or three passes of the bf16
+    kernel), weight gradient on the LDS-window weight-gradient kernel — against torch conv1d in fp64."""
+    import math
+    import torch.nn.functional as F
+    from applecider_amd import hipops as H
+    gen = torch.Generator().manual_seed(L + Cin)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64).requires_grad_()
+    ws = [(torch.randn(Cout, Cin, k, generator=gen, dtype=torch.float64) / math.sqrt(Cin * k)).requires_grad_()
+          for k in ks]
+    bs = [torch.randn(Cout, generator=gen, dtype=torch.float64).requires_grad_() for _ in ks]
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    go = torch.randn(*y.shape, generator=gen, dtype=torch.float64)
+    y.backward(go)
+    xd = x.detach().float().permute(0, 2, 1).contiguous().to(dev).requires_grad_()
+    wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+    bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
+    H._CONVWIN_X3_FUSED = fused
+    try:
+        yd = H.conv_group1d(xd, ks, wd, bd)
+        yd.backward(go.float().permute(0, 2, 1).contiguous().to(dev))
+    finally:
+        H._CONVWIN_X3_FUSED = True
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    tol = 5e-5
+    assert rel(yd.permute(0, 2, 1), y.detach()) <= tol
+    assert rel(xd.grad.permute(0, 2, 1), x.grad) <= tol
+    for i, k in enumerate(ks):
+        assert rel(wd[i].grad.reshape(Cout, k, Cin).permute(0, 2, 1), ws[i].grad) <= tol, f"dw{i}"
+        assert rel(bd[i].grad, bs[i].grad) <= tol
