@@ -12,6 +12,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
+# the same sources built with IEEE fp16 as the 16-bit operand format (csrc/Makefile, ac_common.h):
+# the inference library behind hipops.set_math("f16") (BASELINE configs[4])
+LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libapplecider_hip_f16.so")
 
 AC_GEMM_NT, AC_GEMM_NN, AC_GEMM_TN = 0, 1, 2
 AC_EINVAL = -22
@@ -140,28 +143,45 @@ SIGNATURES = {
 _RESTYPES = {"ac_strerror": C.c_char_p}
 
 _lib = None
+_libs: dict = {}
+_variant = "bf16"
 
 
 class HipLibraryMissing(RuntimeError):
     pass
 
 
-def load():
-    """Load the in-tree shared library (once).  Raises HipLibraryMissing loudly."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _load_path(path: str):
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  applecider_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     if lib.ac_abi_version() != 1:
         raise HipLibraryMissing(f"ABI version mismatch: {lib.ac_abi_version()} != 1")
+    return lib
+
+
+def select(variant: str):
+    """Which build of the library `load()` hands out: "bf16" (default; training and inference) or
+    "f16" (IEEE fp16 operands, inference only).  hipops.set_math switches it."""
+    global _variant
+    if variant not in ("bf16", "f16"):
+        raise ValueError(variant)
+    _variant = variant
+
+
+def load():
+    """The in-tree shared library of the selected operand format (loaded once each).  Raises
+    HipLibraryMissing loudly."""
+    lib = _libs.get(_variant)
+    if lib is None:
+        lib = _libs[_variant] = _load_path(LIB_PATH_F16 if _variant == "f16" else LIB_PATH)
+    global _lib
     _lib = lib
     return lib
 

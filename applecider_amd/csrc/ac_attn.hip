@@ -35,10 +35,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int ATT_TMAX = 288;   // padded tokens per head (T <= 288)
 
 __device__ __forceinline__ unsigned short a_f2bf(float x) {
-    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+    return ac_f2h(x);
 }
 __device__ __forceinline__ float a_bf2f(unsigned short h) {
-    return __builtin_bit_cast(float, (unsigned)h << 16);
+    return ac_h2f(h);
 }
 
 // element offset of (row, 4-element chunk c) in a [rows][16] bf16 image
@@ -99,10 +99,10 @@ template <bool SPLIT>
 __device__ __forceinline__ f32x16 mma(const bf16x8 &ah, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bl,
                                       f32x16 acc) {
     if (SPLIT) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = AC_MFMA16(al, bh, acc);
+        acc = AC_MFMA16(ah, bl, acc);
     }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return AC_MFMA16(ah, bh, acc);
 }
 
 __device__ __forceinline__ f32x16 zero16() {

@@ -12,6 +12,35 @@
         if (e__ != hipSuccess) return -(int)e__ - 2000; \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit operand format of THIS BUILD of the library.  The training library
+// (libapplecider_hip.so) rounds matrix-core operands and 16-bit hand-overs to bfloat16: 8 exponent
+// bits, so activations and gradients never leave the range.  `make` also builds the same sources with
+// -DAC_HALF_F16 into libapplecider_hip_f16.so, the INFERENCE library of BASELINE configs[4]
+// ("inference-only fused forward, fp16"): IEEE fp16 operands on v_mfma_f32_32x32x16_f16 — the same
+// matrix-core rate, 3 more mantissa bits, forward only (fp16 gradients would underflow).
+// Every conversion in the kernels goes through ac_f2h / ac_h2f / AC_MFMA16.
+// ---------------------------------------------------------------------------------------------
+#include <hip/hip_bf16.h>
+typedef short ac_s16x8 __attribute__((ext_vector_type(8)));
+#ifdef AC_HALF_F16
+typedef _Float16 ac_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short ac_f2h(float x) {
+    return __builtin_bit_cast(unsigned short, (_Float16)x);       // round to nearest even
+}
+__device__ __forceinline__ float ac_h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+#define AC_MFMA16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ac_h8, a), __builtin_bit_cast(ac_h8, b), c, 0, 0, 0)
+#define AC_HALF_NAME "f16"
+#else
+__device__ __forceinline__ unsigned short ac_f2h(float x) {
+    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));   // v_cvt_pk_bf16_f32, RNE
+}
+__device__ __forceinline__ float ac_h2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+#define AC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define AC_HALF_NAME "bf16"
+#endif
+
 static inline bool ac_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 __device__ __forceinline__ float ac_gelu(float x) {

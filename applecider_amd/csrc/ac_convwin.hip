@@ -21,7 +21,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 __device__ __forceinline__ unsigned short win_bf16(float x) {
-    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+    return ac_f2h(x);
 }
 
 struct ConvWinParams {
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
             const int chunk = 2 * s + lh;
             const bf16x8 b0 = *(const bf16x8 *)(bt + n0 * 64 + ((chunk ^ ((n0 >> 1) & 7)) << 3));
             const bf16x8 b1 = *(const bf16x8 *)(bt + n1 * 64 + ((chunk ^ ((n1 >> 1) & 7)) << 3));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = AC_MFMA16(a0, b0, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0, b1, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1, b0, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1, b1, acc[1][1]);
         }
     };
     unsigned short *S0 = bst, *S1 = bst + BN * 64;
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(2 * WM * WN * 64, 1) void conv1d_window_ks2_kernel(
             const int chunk = 2 * s + lh;
             const bf16x8 b0 = *(const bf16x8 *)(bt + n0 * 64 + ((chunk ^ ((n0 >> 1) & 7)) << 3));
             const bf16x8 b1 = *(const bf16x8 *)(bt + n1 * 64 + ((chunk ^ ((n1 >> 1) & 7)) << 3));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = AC_MFMA16(a0, b0, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0, b1, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1, b0, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1, b1, acc[1][1]);
         }
     };
     unsigned short *S0 = bst, *S1 = bst + 2 * TILE;
@@ -568,18 +568,18 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                     const bf16x8 b0h = *(const bf16x8 *)(bt + bo0), b1h = *(const bf16x8 *)(bt + bo1);
                     const bf16x8 a0l = *(const bf16x8 *)(win_l + ao0), a1l = *(const bf16x8 *)(win_l + ao1);
                     const bf16x8 b0l = *(const bf16x8 *)(bt + WT + bo0), b1l = *(const bf16x8 *)(bt + WT + bo1);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+                    acc[0][0] = AC_MFMA16(a0l, b0h, acc[0][0]);
+                    acc[0][1] = AC_MFMA16(a0l, b1h, acc[0][1]);
+                    acc[1][0] = AC_MFMA16(a1l, b0h, acc[1][0]);
+                    acc[1][1] = AC_MFMA16(a1l, b1h, acc[1][1]);
+                    acc[0][0] = AC_MFMA16(a0h, b0l, acc[0][0]);
+                    acc[0][1] = AC_MFMA16(a0h, b1l, acc[0][1]);
+                    acc[1][0] = AC_MFMA16(a1h, b0l, acc[1][0]);
+                    acc[1][1] = AC_MFMA16(a1h, b1l, acc[1][1]);
+                    acc[0][0] = AC_MFMA16(a0h, b0h, acc[0][0]);
+                    acc[0][1] = AC_MFMA16(a0h, b1h, acc[0][1]);
+                    acc[1][0] = AC_MFMA16(a1h, b0h, acc[1][0]);
+                    acc[1][1] = AC_MFMA16(a1h, b1h, acc[1][1]);
                 }
             };
             unsigned short *S0 = bst, *S1 = bst + 2 * WT;

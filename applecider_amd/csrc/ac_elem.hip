@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float *__rest
             const float o0 = d.x * g.x, o1 = d.y * g.y;
             if (dyl) *(float2 *)(dyl + r * C + c) = float2{o0, o1};
             if (dyl16) {
-                const unsigned h0 = __builtin_bit_cast(unsigned short, __float2bfloat16(o0));
-                const unsigned h1 = __builtin_bit_cast(unsigned short, __float2bfloat16(o1));
+                const unsigned h0 = ac_f2h(o0);
+                const unsigned h1 = ac_f2h(o1);
                 *(unsigned *)(dyl16 + r * C + c) = h0 | (h1 << 16);
             }
         }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_scalar_kernel(const float 
             sd += d;
             const float o = d * g;
             if (dyl) dyl[r * C + c] = o;
-            if (dyl16) dyl16[r * C + c] = __builtin_bit_cast(unsigned short, __float2bfloat16(o));
+            if (dyl16) dyl16[r * C + c] = ac_f2h(o);
         }
         atomicAdd(&dgamma[c], s);
         if (dbias) atomicAdd(&dbias[c], sd * g);
@@ -341,9 +341,8 @@ __global__ void pad_rows_bf16_kernel(const float *x, unsigned short *y, int B, i
             const f32x4 a = *(const f32x4 *)src, bb = *(const f32x4 *)(src + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                __hip_bfloat16 h0 = __float2bfloat16(a[j]), h1 = __float2bfloat16(bb[j]);
-                o[j] = *reinterpret_cast<short *>(&h0);
-                o[4 + j] = *reinterpret_cast<short *>(&h1);
+                o[j] = (short)ac_f2h(a[j]);
+                o[4 + j] = (short)ac_f2h(bb[j]);
             }
         }
         *(s16x8 *)(y + (int64_t)i * 8) = o;
@@ -358,8 +357,7 @@ __global__ void pad_rows_bf16_scalar_kernel(const float *x, unsigned short *y, i
         int lp = (int)(t % Lp);
         int64_t b = t / Lp;
         int l = lp - pad_lo;
-        __hip_bfloat16 h = __float2bfloat16((l >= 0 && l < L) ? x[(b * L + l) * C + c] : 0.f);
-        y[i] = *reinterpret_cast<unsigned short *>(&h);
+        y[i] = ac_f2h((l >= 0 && l < L) ? x[(b * L + l) * C + c] : 0.f);
     }
 }
 

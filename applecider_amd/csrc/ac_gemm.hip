@@ -38,10 +38,10 @@ struct GemmParams {
 
 // round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
 __device__ __forceinline__ unsigned short epi_bf16(float x) {
-    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+    return ac_f2h(x);
 }
 __device__ __forceinline__ float epi_bf16_to_f32(unsigned short h) {
-    return __builtin_bit_cast(float, (unsigned)h << 16);
+    return ac_h2f(h);
 }
 
 __device__ __forceinline__ int64_t inner_off(const int32_t *goff, int i) {
@@ -353,6 +353,30 @@ struct Loader {
         }
     }
 
+    // Raw form for software pipelines deeper than one tile: nothing consumes the loaded registers in
+    // the iteration that issued them (mask bit i = element group i is inside the operand; applied by
+    // whoever writes the registers to LDS).
+    __device__ __forceinline__ void load_raw(int kt, f32x4 (&v)[4], unsigned &mask) const {
+        if (KC) {
+            const int k = kt * BK + 4 * (t & 7);
+            const bool kv = k < inner_n;
+            const int ktc = kv ? kt : 0;
+            const int64_t ko = kv ? (goff ? (int64_t)ac_gload<int32_t>(goff + ktc) : (int64_t)ktc * BK) : 0;
+            mask = kv ? 0xFu : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ac_gload<f32x4>(ptr + base[i] + (kv ? ko : -4 * (t & 7)));
+        } else {
+            mask = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kg = kt * BK + (t >> 5) + 8 * i;
+                const bool in = kg < outer_n;
+                v[i] = ac_gload<f32x4>(ptr + ac_rowaddr(rows, in ? kg : outer_n - 1) + base[i]);
+                mask |= (ok[i] && in) ? (1u << i) : 0u;
+            }
+        }
+    }
+
     __device__ __forceinline__ void store(float *tile, const f32x4 (&v)[4]) const {
         if (KC) {
             int c = t & 7;
@@ -487,8 +511,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short f2bf(float x) {
-    __hip_bfloat16 b = __float2bfloat16(x);
-    return *reinterpret_cast<unsigned short *>(&b);
+    return ac_f2h(x);
 }
 
 template <bool KC>
@@ -591,10 +614,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             bf16x8 a1 = read_frag_bf16<A_KC>(at, wm * 64 + 32 + li, s, lh);
             bf16x8 b0 = read_frag_bf16<B_KC>(bt, wn * 64 + li, s, lh);
             bf16x8 b1 = read_frag_bf16<B_KC>(bt, wn * 64 + 32 + li, s, lh);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = AC_MFMA16(a0, b0, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0, b1, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1, b0, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1, b1, acc[1][1]);
         }
         if (more) {
             store_bf16<A_KC>(la, sm16 + (cur ^ 1) * 2 * TILE_FLOATS, ra);
@@ -801,7 +824,7 @@ __device__ __forceinline__ void split4(const f32x4 &v, s16x4_t &hi, s16x4_t &lo)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned short h = f2bf(v[j]);
-        const float hf = __builtin_bit_cast(float, (unsigned)h << 16);
+        const float hf = ac_h2f(h);
         hi[j] = (short)h;
         lo[j] = (short)f2bf(v[j] - hf);
     }
@@ -809,12 +832,14 @@ __device__ __forceinline__ void split4(const f32x4 &v, s16x4_t &hi, s16x4_t &lo)
 
 template <bool KC>
 __device__ __forceinline__ void store_x3(const Loader<KC> &L, unsigned short *img_hi, unsigned short *img_lo,
-                                         const f32x4 (&v)[4]) {
+                                         const f32x4 (&v)[4], unsigned mask) {
     const int t = L.t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s16x4_t hi, lo;
-        split4(v[i], hi, lo);
+        const bool in = (mask >> i) & 1u;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        split4(in ? v[i] : zero, hi, lo);
         int off;
         if (KC) {
             const int c = t & 7, r = (t >> 3) + 32 * i;
@@ -881,21 +906,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 ra[4], rb[4];
-    la.load(kt_begin, ra);
-    lb.load(kt_begin, rb);
-    store_x3<A_KC>(la, sm16, sm16 + A_IMG, ra);
-    store_x3<B_KC>(lb, sm16 + 2 * A_IMG, sm16 + 2 * A_IMG + B_IMG, rb);
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) {
-            la.load(kt + 1, ra);
-            lb.load(kt + 1, rb);
-        }
-        const unsigned short *ah = sm16 + cur * STAGE, *al = ah + A_IMG;
+    // Software pipeline, prefetch distance 2 (two register sets, two LDS stages, one barrier per K
+    // tile): while tile kt feeds the matrix cores, tile kt+1 waits in registers and the loads of tile
+    // kt+2 are in flight.  The small-K products of the image / photometry branches run one workgroup
+    // per CU or less, where a distance-1 pipeline exposed the whole L2 latency in every K tile
+    // (1.9 us per 32-deep tile against 0.3 us of MFMA work).  Loads past the K range are clamped and
+    // zero-masked by the loaders, so the steady state needs no data-dependent branch.
+    auto compute = [&](const unsigned short *stage) {
+        const unsigned short *ah = stage, *al = ah + A_IMG;
         const unsigned short *bh = ah + 2 * A_IMG, *bl = bh + B_IMG;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -904,26 +922,48 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
             const bf16x8 a0l = frag_x3<A_KC>(al, wm * 64, s, lane), a1l = frag_x3<A_KC>(al, wm * 64 + 32, s, lane);
             const bf16x8 b0l = frag_x3<B_KC>(bl, wn * 64, s, lane), b1l = frag_x3<B_KC>(bl, wn * 64 + 32, s, lane);
             // cross terms first, the leading term last
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+            acc[0][0] = AC_MFMA16(a0l, b0h, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0l, b1h, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1l, b0h, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1l, b1h, acc[1][1]);
+            acc[0][0] = AC_MFMA16(a0h, b0l, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0h, b1l, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1h, b0l, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1h, b1l, acc[1][1]);
+            acc[0][0] = AC_MFMA16(a0h, b0h, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0h, b1h, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1h, b0h, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1h, b1h, acc[1][1]);
         }
-        if (more) {
-            unsigned short *nx = sm16 + (cur ^ 1) * STAGE;
-            store_x3<A_KC>(la, nx, nx + A_IMG, ra);
-            store_x3<B_KC>(lb, nx + 2 * A_IMG, nx + 2 * A_IMG + B_IMG, rb);
-        }
+    };
+    auto stage_store = [&](unsigned short *stage, const f32x4 (&ra)[4], const f32x4 (&rb)[4], unsigned ma,
+                           unsigned mb) {
+        store_x3<A_KC>(la, stage, stage + A_IMG, ra, ma);
+        store_x3<B_KC>(lb, stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb, mb);
+    };
+    unsigned short *S0 = sm16, *S1 = sm16 + STAGE;
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    unsigned ma0, mb0, ma1, mb1;
+    la.load_raw(kt_begin, ra0, ma0);
+    lb.load_raw(kt_begin, rb0, mb0);
+    stage_store(S0, ra0, rb0, ma0, mb0);
+    __syncthreads();
+    la.load_raw(kt_begin + 1, ra0, ma0);
+    lb.load_raw(kt_begin + 1, rb0, mb0);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        la.load_raw(kt + 2, ra1, ma1);
+        lb.load_raw(kt + 2, rb1, mb1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S0);
+        stage_store(S1, ra0, rb0, ma0, mb0);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 >= kt_end) break;
+        la.load_raw(kt + 3, ra0, ma0);
+        lb.load_raw(kt + 3, rb0, mb0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S1);
+        stage_store(S0, ra1, rb1, ma1, mb1);
+        __syncthreads();
     }
 
     if (p.vec_epi == 2)
@@ -1019,10 +1059,10 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
                 b0 = frag_kc16(bt, wn * 64 + li, s, lh);
                 b1 = frag_kc16(bt, wn * 64 + 32 + li, s, lh);
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = AC_MFMA16(a0, b0, acc[0][0]);
+            acc[0][1] = AC_MFMA16(a0, b1, acc[0][1]);
+            acc[1][0] = AC_MFMA16(a1, b0, acc[1][0]);
+            acc[1][1] = AC_MFMA16(a1, b1, acc[1][1]);
         }
     };
     unsigned short *S0 = sm, *S1 = sm + Cfg::STAGE;

@@ -282,9 +282,7 @@ __device__ __forceinline__ float ac_group_sum(float v) {
 }
 
 __device__ __forceinline__ unsigned short ln_bf16(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
-    return (unsigned short)(u >> 16);
+    return ac_f2h(x);
 }
 
 // 4 consecutive values of a row that is fp32 or (is16) bf16 in memory; ld in elements
@@ -292,10 +290,10 @@ __device__ __forceinline__ f32x4 ln_load4(const float *base, int64_t elem, int i
     if (is16) {
         const ushort4 h = *(const ushort4 *)((const unsigned short *)base + elem);
         f32x4 v;
-        v[0] = __builtin_bit_cast(float, (unsigned)h.x << 16);
-        v[1] = __builtin_bit_cast(float, (unsigned)h.y << 16);
-        v[2] = __builtin_bit_cast(float, (unsigned)h.z << 16);
-        v[3] = __builtin_bit_cast(float, (unsigned)h.w << 16);
+        v[0] = ac_h2f(h.x);
+        v[1] = ac_h2f(h.y);
+        v[2] = ac_h2f(h.z);
+        v[3] = ac_h2f(h.w);
         return v;
     }
     return *(const f32x4 *)(base + elem);
@@ -608,10 +606,7 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
             const float2 v = *(const float2 *)(x + r * ldx + c);
             a0 += v.x;
             a1 += v.y;
-            unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y);
-            u0 += 0x7fffu + ((u0 >> 16) & 1u);
-            u1 += 0x7fffu + ((u1 >> 16) & 1u);
-            *(unsigned *)(y16 + r * ldy + c) = (u0 >> 16) | (u1 & 0xffff0000u);
+            *(unsigned *)(y16 + r * ldy + c) = (unsigned)ac_f2h(v.x) | ((unsigned)ac_f2h(v.y) << 16);
         }
     }
     part[ph][2 * cl] = a0;
@@ -642,15 +637,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short *
         for (; r + 4 < r1; r += 8) {
             const unsigned u = *(const unsigned *)(x + r * ldx + c);
             const unsigned w = *(const unsigned *)(x + (r + 4) * ldx + c);
-            a0 += __builtin_bit_cast(float, u << 16);
-            a1 += __builtin_bit_cast(float, u & 0xffff0000u);
-            b0 += __builtin_bit_cast(float, w << 16);
-            b1 += __builtin_bit_cast(float, w & 0xffff0000u);
+            a0 += ac_h2f((unsigned short)(u & 0xffffu));
+            a1 += ac_h2f((unsigned short)(u >> 16));
+            b0 += ac_h2f((unsigned short)(w & 0xffffu));
+            b1 += ac_h2f((unsigned short)(w >> 16));
         }
         if (r < r1) {
             const unsigned u = *(const unsigned *)(x + r * ldx + c);
-            a0 += __builtin_bit_cast(float, u << 16);
-            a1 += __builtin_bit_cast(float, u & 0xffff0000u);
+            a0 += ac_h2f((unsigned short)(u & 0xffffu));
+            a1 += ac_h2f((unsigned short)(u >> 16));
         }
     }
     part[ph][2 * cl] = a0 + b0;

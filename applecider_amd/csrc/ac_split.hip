@@ -12,9 +12,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short s_f2bf(float x) {
-    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));
+    return ac_f2h(x);
 }
-__device__ __forceinline__ float s_bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ float s_bf2f(unsigned short h) { return ac_h2f(h); }
 
 __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, s16x8 &hi, s16x8 &lo) {
 #pragma unroll

@@ -140,10 +140,10 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l[i], b_h[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_l[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = AC_MFMA16(a_l[i], b_h[j], acc[i][j]);
+                        acc[i][j] = AC_MFMA16(a_h[i], b_l[j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_h[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = AC_MFMA16(a_h[i], b_h[j], acc[i][j]);
                 }
         }
     };

@@ -23,7 +23,10 @@ from ._lib import (ACT_CODES, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TAN
 _MATH = _lib.MATH_F32
 
 
-_MATH_NAMES = {"f32": _lib.MATH_F32, "bf16": _lib.MATH_BF16, "bf16x3": _lib.MATH_BF16X3}
+_MATH_NAMES = {"f32": _lib.MATH_F32, "bf16": _lib.MATH_BF16, "bf16x3": _lib.MATH_BF16X3, "f16": _lib.MATH_BF16}
+_MODE = "f32"
+_H16 = torch.bfloat16    # torch dtype that labels the 16-bit buffers of the loaded library's operand format
+_MATH_EPOCH = 0          # bumped by set_math: 16-bit parameter mirrors made under another mode are stale
 # modes whose logits are held to the path's parity bar (<= 1e-3 relative to the CPU oracle, identical
 # argmax) by tests/test_gpu_parity_modes.py; plain bf16 is the fast, unqualified mode
 QUALIFIED_MODES = ("f32", "bf16x3")
@@ -35,13 +38,28 @@ def set_math(mode: str):
       'bf16x3'  split bf16: fp32 data flow, every product = 3 bf16 MFMAs on (hi, lo) operand halves,
                 ~2^-16 relative per product (the qualified fast mode)
       'bf16'    bf16 MFMA inputs (one rounding to 8 mantissa bits per operand), bf16 operand copies and
-                bf16-only hand-overs in HBM, fp32 accumulate / parameters / optimizer state"""
-    global _MATH
+                bf16-only hand-overs in HBM, fp32 accumulate / parameters / optimizer state
+      'f16'     INFERENCE ONLY (BASELINE configs[4]): the data flow of 'bf16' on the fp16 build of the
+                library (libapplecider_hip_f16.so: IEEE fp16 operands, v_mfma_f32_32x32x16_f16); backward
+                through this mode raises"""
+    global _MATH, _MODE, _H16, _MATH_EPOCH
     _MATH = _MATH_NAMES[mode]
+    _lib.select("f16" if mode == "f16" else "bf16")
+    _H16 = torch.float16 if mode == "f16" else torch.bfloat16
+    if mode != _MODE:
+        _MATH_EPOCH += 1
+        _step_cache.clear()
+    _MODE = mode
 
 
 def get_math() -> str:
-    return {v: k for k, v in _MATH_NAMES.items()}[_MATH]
+    return _MODE
+
+
+def _no_f16_backward():
+    if _MODE == "f16":
+        raise RuntimeError("math mode 'f16' is inference only (fp16 gradients underflow): train in "
+                           "'bf16x3' / 'bf16' / 'f32'")
 
 
 # --------------------------------------------------------------------------- helpers
@@ -144,7 +162,7 @@ def _side16_alloc(shape, C: int, device):
     """bf16 side output of a producer kernel (bf16 math mode only)."""
     if not bf16_operands() or not _ln_sub_shape(C):
         return None
-    return torch.empty(shape, device=device, dtype=torch.bfloat16)
+    return torch.empty(shape, device=device, dtype=_H16)
 
 
 def cast16_act(x: torch.Tensor, K: int) -> torch.Tensor:
@@ -156,7 +174,7 @@ def cast16_act(x: torch.Tensor, K: int) -> torch.Tensor:
 
 
 def cast16(t: torch.Tensor) -> torch.Tensor:
-    y = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    y = torch.empty(t.shape, device=t.device, dtype=_H16)
     _lib.check(_lib_().ac_cast_bf16(_p(t), _p(y), t.numel(), _stream()), "ac_cast_bf16")
     return y
 
@@ -173,7 +191,7 @@ def transpose_cast_segments(src, dst, segs, nseg, tiles):
 def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
     """[R, C] fp32 -> [C, R] bf16."""
     R, Cc = t2d.shape
-    y = torch.empty(Cc, R, device=t2d.device, dtype=torch.bfloat16)
+    y = torch.empty(Cc, R, device=t2d.device, dtype=_H16)
     _lib.check(_lib_().ac_transpose_cast_bf16(_p(t2d), Cc, _p(y), R, R, Cc, _stream()),
                "ac_transpose_cast_bf16")
     return y
@@ -181,7 +199,7 @@ def cast16_T(t2d: torch.Tensor) -> torch.Tensor:
 
 def split16(t: torch.Tensor):
     """(hi, lo) bf16 planes of an fp32 tensor: hi = bf16(t), lo = bf16(t - hi)  (math mode bf16x3)."""
-    hi = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    hi = torch.empty(t.shape, device=t.device, dtype=_H16)
     lo = torch.empty_like(hi)
     _lib.check(_lib_().ac_split_bf16(_p(t), _p(hi), _p(lo), t.numel(), _stream()), "ac_split_bf16")
     return hi, lo
@@ -190,7 +208,7 @@ def split16(t: torch.Tensor):
 def split16_T(t2d: torch.Tensor):
     """[R, C] fp32 -> (hi, lo) planes of the transpose [C, R]."""
     R, Cc = t2d.shape
-    hi = torch.empty(Cc, R, device=t2d.device, dtype=torch.bfloat16)
+    hi = torch.empty(Cc, R, device=t2d.device, dtype=_H16)
     lo = torch.empty_like(hi)
     _lib.check(_lib_().ac_transpose_split_bf16(_p(t2d), Cc, _p(hi), _p(lo), R, R, Cc, _stream()),
                "ac_transpose_split_bf16")
@@ -206,7 +224,7 @@ def split16_wT(w2d):
 
 
 def _pad_rows_split(x, B, L, Cn, pad_lo, Lp):
-    hi = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.bfloat16)
+    hi = torch.empty(B, Lp, Cn, device=x.device, dtype=_H16)
     lo = torch.empty_like(hi)
     _lib.check(_lib_().ac_pad_rows_split(_p(x), _p(hi), _p(lo), B, L, Cn, pad_lo, Lp, _stream()),
                "ac_pad_rows_split")
@@ -296,7 +314,7 @@ def _mirror(w, transposed: bool):
     # stale when the optimizer stepped (raw-pointer update: dirty flag), when the flat buffer was
     # written through torch (broadcast), or when this parameter was (load_state_dict, init)
     if (fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
-            or fp.mirror_pver[ent[2]] != w._version):
+            or fp.mirror_pver[ent[2]] != w._version or getattr(fp, "mirror_epoch", -1) != _MATH_EPOCH):
         fp.refresh_mirrors()
     if transposed:
         if w.dim() != 2:
@@ -332,7 +350,8 @@ def ensure_mirrors(fp):
     refresh while another is already reading the mirrors."""
     if fp is None or fp.flat is None or not fp.flat.is_cuda or not bf16_operands():
         return
-    stale = fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
+    stale = (fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
+             or getattr(fp, "mirror_epoch", -1) != _MATH_EPOCH)
     if not stale:
         stale = any(v != p._version for v, p in zip(fp.mirror_pver, fp.params))
     if stale:
@@ -574,6 +593,7 @@ class _Linear(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _no_f16_backward()
         x2, w, aux, colscale = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
@@ -597,7 +617,7 @@ class _Linear(Function):
             bsink = _sink(ctx.bp) if (ctx.has_b and ctx.needs_input_grad[2]) else None
             if bsink is not None and N % 2 == 0:
                 # one pass over g: the bf16 operand copy and the bias gradient (into its sink)
-                g16 = torch.empty(M, N, device=dy.device, dtype=torch.bfloat16)
+                g16 = torch.empty(M, N, device=dy.device, dtype=_H16)
                 _lib.check(_lib_().ac_cast_bf16_colsum(_p(g), N, _p(g16), N, _p(bsink), M, N, 1,
                                                        _stream()), "ac_cast_bf16_colsum")
                 _grad_written(ctx.bp)
@@ -610,7 +630,7 @@ class _Linear(Function):
                 # the producer of x reads its output gradient in bf16 (LayerNorm backward of the conv
                 # bank): write only that; the fp32 tensor autograd carries is a placeholder
                 wT16 = cast16_wT(ctx.wp if ctx.wp.shape == w.shape else w)
-                dx16 = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
+                dx16 = torch.empty(M, K, device=dy.device, dtype=_H16)
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(None, K), c16=dx16,
                      ld_c16=K, math=_lib.MATH_BF16_IN)
                 dx = _mark16only(dx, dx16.reshape(ctx.shape_x))
@@ -673,7 +693,7 @@ class _MLP(Function):
         x16, w1_16, w2_16 = cast16_act(x, K), cast16_w(w1), cast16_w(w2)
         need_grad = any(ctx.needs_input_grad)
         pre1 = torch.empty(M, Hd, device=dev, dtype=torch.float32) if (act == ACT_GELU and need_grad) else None
-        g16 = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+        g16 = torch.empty(M, Hd, device=dev, dtype=_H16)
         gemm(AC_GEMM_NT, M, Hd, K, mat(_p(x16), K), mat(_p(w1_16), K), mat(None, Hd), bias=b1, act=act,
              pre_out=pre1, ld_pre=Hd, c16=g16, ld_c16=Hd, drop_p=p1, drop_seed=seed1,
              math=_lib.MATH_BF16_IN)
@@ -691,6 +711,7 @@ class _MLP(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _no_f16_backward()
         x16, w1, w2, pre1, g16, pre2, colscale = ctx.saved_tensors
         w1p, b1p, w2p, b2p = ctx.params
         Hd, K = w1.shape
@@ -706,7 +727,7 @@ class _MLP(Function):
             _lib.check(lib.ac_dropout(_p(dy2), _p(g2), M * N, ctx.p2, ctx.seed2, 0, st), "ac_dropout")
         dcs = db2 = None
         b2sink = _sink(b2p) if (b2p is not None and ctx.needs_input_grad[4]) else None
-        g2_16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        g2_16 = torch.empty(M, N, device=dev, dtype=_H16)
         if colscale is not None:
             # layer scale: bf16 gradient of the linear output, dgamma and the bias gradient in one pass
             dcs = torch.zeros_like(colscale)
@@ -727,7 +748,7 @@ class _MLP(Function):
         # ---- dW2 = g2^T @ hidden
         dw2 = _weight_grad(w2p, g2_16, N, g16, Hd, M, ctx.needs_input_grad[3])
         # ---- hidden gradient, bf16 only: (g2 @ W2) * act'(.) [* dropout1 mask]
-        dh16 = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+        dh16 = torch.empty(M, Hd, device=dev, dtype=_H16)
         w2T16 = cast16_wT(w2p if w2p.shape == w2.shape else w2)
         if ctx.act == ACT_GELU:
             gemm(AC_GEMM_NT, M, Hd, N, mat(_p(g2_16), N), mat(_p(w2T16), N), mat(None, Hd),
@@ -832,6 +853,7 @@ class _LayerNorm(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _no_f16_backward()
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dy = _chk(dy, "dy")
         Cn = x.shape[-1]
@@ -1286,7 +1308,7 @@ def _pad_rows(x, B, L, Cn, pad_lo, Lp):
 
 
 def _pad_rows16(x, B, L, Cn, pad_lo, Lp):
-    y = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(B, Lp, Cn, device=x.device, dtype=_H16)
     _lib.check(_lib_().ac_pad_rows_bf16(_p(x), _p(y), B, L, Cn, pad_lo, Lp, _stream()),
                "ac_pad_rows_bf16")
     return y
@@ -1331,7 +1353,7 @@ class _ConvGroup1d(Function):
         # are written once by the conv epilogues and read by LayerNorm forward and backward (4.7 GB of
         # HBM traffic per step at the benchmark shape when kept in fp32)
         cat16 = ctx.cat16 = bool(b16 and ln_gamma is not None and _ln_sub_shape(Ncat) and _CAT16)
-        ycat = torch.empty(B, L, Ncat, device=dev, dtype=torch.bfloat16 if cat16 else torch.float32)
+        ycat = torch.empty(B, L, Ncat, device=dev, dtype=_H16 if cat16 else torch.float32)
         if Cin == 1:
             if L % 8:
                 raise ValueError("Cin == 1 path needs L % 8 == 0")
@@ -1423,6 +1445,7 @@ class _ConvGroup1d(Function):
 
     @staticmethod
     def backward(ctx, dycat):
+        _no_f16_backward()
         B, L, Cin, Cout, Pmax = ctx.dims
         ksizes = ctx.ksizes
         nconv = len(ksizes)
@@ -1455,13 +1478,13 @@ class _ConvGroup1d(Function):
             direct16 = b16 and fuse_bias and _ln_sub_shape(Ncat)
             dpre, seg = None, (0, 0, 0)
             if direct16 and need_dx:
-                dypad = torch.empty(B, Lpd, Ncat, device=dev, dtype=torch.bfloat16)
+                dypad = torch.empty(B, Lpd, Ncat, device=dev, dtype=_H16)
                 if Pmax > 0:
                     dypad[:, :Pmax].zero_()
                     dypad[:, Pmax + L:].zero_()
                 out16, seg = dypad, (L, Lpd, Pmax)
             elif direct16:
-                dyop = torch.empty(B * L, Ncat, device=dev, dtype=torch.bfloat16)
+                dyop = torch.empty(B * L, Ncat, device=dev, dtype=_H16)
                 out16 = dyop
             else:
                 dpre, out16 = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32), None

@@ -79,8 +79,8 @@ class FlatParameters:
 
     def refresh_mirrors(self):
         """bf16 copies of all parameters (and the transposes of the 2-D ones) in two launches."""
-        if self.flat16 is None:
-            self.flat16 = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
+        if self.flat16 is None or self.flat16.dtype != H._H16:
+            self.flat16 = torch.empty(self.flat.numel(), device=self.flat.device, dtype=H._H16)
             self.flatT16 = torch.empty_like(self.flat16)
             segs, tiles = [], 0
             for p, off in zip(self.params, self.offsets):
@@ -95,6 +95,7 @@ class FlatParameters:
         if self._segs is not None:
             H.transpose_cast_segments(self.flat, self.flatT16, self._segs, self._nseg, self._tiles)
         self.mirror_dirty, self.mirror_version = False, self.flat._version
+        self.mirror_epoch = H._MATH_EPOCH
         self.mirror_pver = [p._version for p in self.params]
 
     def ensure(self):

@@ -79,3 +79,50 @@ def test_graph_logits_match_oracle(dev):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 1e-3, err
     assert torch.equal(got.argmax(1), ref.argmax(1))
+
+
+def test_fp16_inference_b2048_graph(dev):
+    """BASELINE configs[4] as stated: inference-only fused forward, batch 2048, fp16 operands
+    (libapplecider_hip_f16.so: v_mfma_f32_32x32x16_f16), hipGraph-captured.  Graph == eager bit for bit,
+    probabilities sum to 1, a short batch is padded, scores agree with the fp32 matrix-core mode within
+    fp16 operand rounding, and backward through the mode is refused."""
+    from applecider_amd import hipops as H
+    from applecider_amd.inference import GraphedClassifier
+    from applecider_amd.models.applecider import AppleCider
+    B = 2048
+    torch.manual_seed(5)
+    net = AppleCider(dict(CFG)).to(dev)
+    net.optimizer.prepare()
+    b = _batch(B, 31)
+    H.set_math("f16")
+    try:
+        assert H.get_math() == "f16" and H._H16 == torch.float16
+        gc = GraphedClassifier(net, batch_size=B, use_probabilities=True)
+        got = gc.predict(b).clone()
+        ref16 = gc.eager(b)
+        assert got.shape == (B, 5)
+        assert torch.equal(got, ref16), (got - ref16).abs().max()
+        assert torch.allclose(got.sum(1), torch.ones(B, device=dev), atol=1e-5)
+        short = {k: v[:100] for k, v in b.items()}
+        assert torch.allclose(gc.predict(short), got[:100], rtol=0, atol=1e-6)
+        # training through fp16 operands is refused
+        x = torch.randn(64, 128, device=dev, requires_grad=True)
+        w = torch.nn.Parameter(torch.randn(128, 128, device=dev))
+        with pytest.raises(RuntimeError, match="inference only"):
+            H.linear(x, w).sum().backward()
+    finally:
+        H.set_math("f32")
+    # against the exact fp32 matrix-core mode on the first 256 alerts
+    gc32 = GraphedClassifier(net, batch_size=256, use_probabilities=True)
+    ref = gc32.predict({k: v[:256] for k, v in b.items()}).clone()
+    diff = (got[:256] - ref).abs().max().item()
+    agree = int((got[:256].argmax(1) == ref.argmax(1)).sum())
+    print(f"[fp16 inference] max |dp| vs fp32 = {diff:.2e}, argmax agreement {agree}/256")
+    assert diff <= 2e-2 and agree >= 250
+    H.set_math("bf16")
+    try:   # the same library switch back: bf16 mirrors are rebuilt, not reused from the fp16 epoch
+        gcb = GraphedClassifier(net, batch_size=256, use_probabilities=True)
+        refb = gcb.predict({k: v[:256] for k, v in b.items()}).clone()
+        assert (refb - ref).abs().max().item() <= 6e-2
+    finally:
+        H.set_math("f32")

@@ -347,9 +347,10 @@ def test_cabi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ac_rowmap", "ac_mat", "ac_gemm_desc", "ac_adam_seg", "ac_stream_t"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), name
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16):   # bf16 (training) and fp16 (inference) builds
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), (path, name)
     loaded = _lib.load()
     assert loaded.ac_abi_version() == 1
     assert b"invalid" in loaded.ac_strerror(-22)
