@@ -105,6 +105,26 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 &ah, const bf16x8 &al, const 
     return AC_MFMA16(ah, bh, acc);
 }
 
+// Dropout decisions of the 16 score elements this lane holds of a 32x32 tile, as a bit mask.  The same
+// decision as ac_rand01(seed, idx) >= p_drop of the scalar kernels, in integers: rand01 = (hash >> 8) *
+// 2^-24 exactly, so u >= p  <=>  (hash >> 8) >= ceil(p * 2^24).  `base` = index of element (row 0) and
+// `stride` = index step per tile row; rows follow the accumulator map (e & 3) + 8 (e >> 2) + 4 lh.
+__device__ __forceinline__ unsigned keep_bits(uint64_t seed, uint64_t base, uint64_t stride, int lh, unsigned thr,
+                                              int ngroups) {
+    unsigned bits = 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < ngroups) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint64_t idx = base + (uint64_t)(8 * g + 4 * lh + e) * stride;
+                bits |= ((ac_hash32(seed, idx) >> 8) >= thr ? 1u : 0u) << (4 * g + e);
+            }
+        }
+    }
+    return bits;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -149,6 +169,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
     __syncthreads();
 
     const float inv_keep = 1.0f / (1.0f - p_drop);
+    const unsigned thr = (unsigned)ceilf(p_drop * 16777216.0f);
     for (int qb = wave; qb < NB; qb += 4) {
         const int q = qb * 32 + li;
         float qv[8];
@@ -224,6 +245,9 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
         for (int kb = 0; kb < NB; ++kb) {
             const f32x16 S = scores(kb);
             float pv[16];
+            const int ng = (T - kb * 32 + 7) >> 3;   // key groups of 8 that hold a key < T (wave-uniform)
+            unsigned keep = 0xFFFFu;
+            if (DROP) keep = keep_bits(seed, rbase + (uint64_t)(kb * 32), 1, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
-                        if (DROP) p = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? p * inv_keep : 0.f;
+                        if (DROP) p = ((keep >> (4 * g + e)) & 1u) ? p * inv_keep : 0.f;
                         pv[4 * g + e] = p;
                     }
                 } else {
@@ -312,6 +336,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
     }
     __syncthreads();
     const float inv_keep = 1.0f / (1.0f - p_drop);
+    const unsigned thr = (unsigned)ceilf(p_drop * 16777216.0f);
 
     // ---- phase A: queries on the lanes -> dQ^T[d, query] = K^T . dS^T
     for (int qb = wave; qb < NB; qb += 4) {
@@ -336,6 +361,9 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
             const f32x16 S = mma<SPLIT>(kh, kl, qh, ql, zero16());    // S^T[key, query]
             const f32x16 dP = mma<SPLIT>(vh, vl, gh, gl, zero16());   // dP~^T[key, query]
             float ds[16];
+            const int ng = (T - kb * 32 + 7) >> 3;
+            unsigned keep = 0xFFFFu;
+            if (DROP) keep = keep_bits(seed, rbase + (uint64_t)(kb * 32), 1, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
                         float ks = 1.f;
-                        if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
+                        if (DROP) ks = ((keep >> (4 * g + e)) & 1u) ? inv_keep : 0.f;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
                     }
                 } else {
@@ -397,6 +425,9 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
             const f32x16 S = mma<SPLIT>(qh, ql, kh, kl, zero16());    // S[query, key]
             const f32x16 dP = mma<SPLIT>(gh, gl, vh, vl, zero16());   // dP~[query, key]
             float pt[16], ds[16];
+            const int ng = (T - qb * 32 + 7) >> 3;
+            unsigned keep = 0xFFFFu;
+            if (DROP) keep = keep_bits(seed, (bh * T + (uint64_t)(qb * 32)) * T + (uint64_t)key, (uint64_t)T, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int q0 = qb * 32 + 8 * g + 4 * lh;
@@ -406,9 +437,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const float p = kvalid ? __expf(S[4 * g + e] - l4[e]) : 0.f;
                         float ks = 1.f;
-                        if (DROP)
-                            ks = ac_rand01(seed, (bh * T + (uint64_t)(q0 + e)) * T + (uint64_t)key) >= p_drop
-                                     ? inv_keep : 0.f;
+                        if (DROP) ks = ((keep >> (4 * g + e)) & 1u) ? inv_keep : 0.f;
                         pt[4 * g + e] = p * ks;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - d4[e]);
                     }

@@ -454,7 +454,9 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     """dw[Cout, k*Cin] += conv weight gradient through the LDS-window kernel (ac_conv1d_wgrad_bf16).
     dy / x are bf16 tensors (dy_lo / x_lo: the lo planes in split-bf16 mode, else None).  False when
     the shape is not covered (the caller then runs the generic TN product)."""
-    if not _WGRAD_WIN or k < 7 or L % 64 or Cout % 128 or Cin % 64:
+    # bf16: short kernels (k < 7) keep the generic TN product (a chunk of 8 taps would be mostly empty);
+    # split-bf16: every k, so that a covered conv bank never needs the fp32 padded input
+    if not _WGRAD_WIN or (k < 7 and dy_lo is None) or L % 64 or Cout % 128 or Cin % 64:
         return False
     d = _lib.WgradDesc()
     d.dy, d.dy_batch_stride, d.dy_row_stride = _p(dy), dy_batch_stride, dy_row_stride
@@ -1392,16 +1394,21 @@ class _ConvGroup1d(Function):
             if Cin % 32:
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
             Lp = L + 2 * Pmax
-            xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
-            # split-bf16 mode: the conv products run on the LDS-window kernel over (hi, lo) planes of the
-            # padded input and of the taps (3 passes); the fp32 copy stays for the weight-gradient product
+            # split-bf16 mode: the conv products run on the LDS-window kernels over (hi, lo) planes of the
+            # padded input and of the taps.  When every product of this bank (forward, input gradient,
+            # weight gradient) is covered by them, the fp32 padded copy is not built at all.
             xplanes = _pad_rows_split(x, B, L, Cin, Pmax, Lp) if (x3_mode() and _CONVWIN and Cin % 8 == 0) else None
+            planes_only = bool(xplanes is not None and _CONVWIN_X3_FUSED and _WGRAD_WIN and L % 128 == 0
+                               and Cin % 64 == 0 and Cout % 128 == 0)
+            xpad = None if planes_only else (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 if xplanes is not None and conv_window_x3(
                         xplanes, Lp * Cin, Cin, 0, off, B, L, Cin, k, split16_w(ws[j]), k * Cin, Cin, False, Cout,
                         _p(ycat, j * Cout), Ncat, bs[j], False):
                     continue
+                if xpad is None:
+                    raise RuntimeError("split-bf16 conv bank: the window kernel refused a shape it covers")
                 wop = cast16_w(ws[j]) if b16 else ws[j]
                 if cat16:
                     if conv_window(xpad, Lp * Cin, Cin, 0, off, B, L, Cin, k, wop, k * Cin, Cin, False,
@@ -1595,6 +1602,8 @@ class _ConvGroup1d(Function):
                     done = conv_wgrad(dyplanes[0], dyplanes[1], Lpd * Ncat, Ncat, Pmax, j * Cout,
                                       ctx.xplanes[0], ctx.xplanes[1], Lp * Cin, Cin, off, Lp, B, L, Cout, Cin, k, dw)
                 if not done:
+                    if xpad is None:
+                        raise RuntimeError("split-bf16 conv bank: the weight-gradient kernel refused a covered shape")
                     tile_, split_ = _tn_plan(Cout, k * Cin, B * L) if b16 else (0, _split_for(Cout, k * Cin, B * L))
                     gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),
                          mat(_p(xpad, off * Cin), r1=L, r2=L, s1=Lp * Cin, s3=Cin),
