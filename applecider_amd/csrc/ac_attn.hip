@@ -3,7 +3,7 @@
 // 73-79: d_model 128, 8 heads -> d_head 16, T = L + 1 <= 258 tokens, src_key_padding_mask, dropout on
 // the attention weights in training).
 //
-// One 256-thread workgroup per (sample, head).  K and V (backward: also Q*scale and dO) of that head
+// One 512-thread workgroup per (sample, head).  K and V (backward: also Q*scale and dO) of that head
 // sit in LDS as [token][16] bf16 images (32-byte rows, the two 16-byte halves of a row swapped on
 // every second group of 8 rows so that the ds_read_b128 row reads are bank-conflict free); a wave
 // owns 32-token blocks.  All contractions are v_mfma_f32_32x32x16_bf16 tiles:
@@ -33,6 +33,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ATT_TMAX = 288;   // padded tokens per head (T <= 288)
+constexpr int ATT_NT = 512;     // 8 waves: T = 129 pads to 5 blocks of 32 tokens (4 waves would share them 2/1/1/1)
 
 __device__ __forceinline__ unsigned short a_f2bf(float x) {
     return ac_f2h(x);
@@ -105,26 +106,6 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 &ah, const bf16x8 &al, const 
     return AC_MFMA16(ah, bh, acc);
 }
 
-// Dropout decisions of the 16 score elements this lane holds of a 32x32 tile, as a bit mask.  The same
-// decision as ac_rand01(seed, idx) >= p_drop of the scalar kernels, in integers: rand01 = (hash >> 8) *
-// 2^-24 exactly, so u >= p  <=>  (hash >> 8) >= ceil(p * 2^24).  `base` = index of element (row 0) and
-// `stride` = index step per tile row; rows follow the accumulator map (e & 3) + 8 (e >> 2) + 4 lh.
-__device__ __forceinline__ unsigned keep_bits(uint64_t seed, uint64_t base, uint64_t stride, int lh, unsigned thr,
-                                              int ngroups) {
-    unsigned bits = 0u;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g < ngroups) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint64_t idx = base + (uint64_t)(8 * g + 4 * lh + e) * stride;
-                bits |= ((ac_hash32(seed, idx) >> 8) >= thr ? 1u : 0u) << (4 * g + e);
-            }
-        }
-    }
-    return bits;
-}
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -141,7 +122,7 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
 }
 
 template <bool SPLIT, bool DROP>
-__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restrict__ qkv,
+__global__ __launch_bounds__(ATT_NT) void mha_fwd_mfma_kernel(const float *__restrict__ qkv,
                                                            const uint8_t *__restrict__ pad,
                                                            float *__restrict__ out, float *__restrict__ lse,
                                                            int T, int H, float p_drop, uint64_t seed) {
@@ -155,7 +136,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
     const float *base = qkv + (int64_t)b * T * 3 * D + h * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
 
-    for (int i = t; i < Tp * 4; i += 256) {
+    for (int i = t; i < Tp * 4; i += ATT_NT) {
         const int tok = i >> 2, c = i & 3;
         f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
         if (tok < T) {
@@ -165,12 +146,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
         img_store4<SPLIT>(Kh, Kl, tok, c, kv);
         img_store4<SPLIT>(Vh, Vl, tok, c, vv);
     }
-    for (int i = t; i < Tp; i += 256) vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
+    for (int i = t; i < Tp; i += ATT_NT) vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
     __syncthreads();
 
     const float inv_keep = 1.0f / (1.0f - p_drop);
-    const unsigned thr = (unsigned)ceilf(p_drop * 16777216.0f);
-    for (int qb = wave; qb < NB; qb += 4) {
+    for (int qb = wave; qb < NB; qb += ATT_NT / 64) {
         const int q = qb * 32 + li;
         float qv[8];
         {
@@ -245,9 +225,6 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
         for (int kb = 0; kb < NB; ++kb) {
             const f32x16 S = scores(kb);
             float pv[16];
-            const int ng = (T - kb * 32 + 7) >> 3;   // key groups of 8 that hold a key < T (wave-uniform)
-            unsigned keep = 0xFFFFu;
-            if (DROP) keep = keep_bits(seed, rbase + (uint64_t)(kb * 32), 1, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
@@ -256,7 +233,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
-                        if (DROP) p = ((keep >> (4 * g + e)) & 1u) ? p * inv_keep : 0.f;
+                        if (DROP) p = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? p * inv_keep : 0.f;
                         pv[4 * g + e] = p;
                     }
                 } else {
@@ -290,7 +267,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float *__restri
 }
 
 template <bool SPLIT, bool DROP>
-__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
+__global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
     const float *__restrict__ dout, const float *__restrict__ qkv, const uint8_t *__restrict__ pad,
     const float *__restrict__ out, const float *__restrict__ lse, float *__restrict__ dqkv, int T, int H,
     float p_drop, uint64_t seed) {
@@ -311,7 +288,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     const uint64_t bh = (uint64_t)b * H + h;
 
-    for (int i = t; i < Tp * 4; i += 256) {   // Tp*4 is a multiple of 128: whole waves stay together
+    for (int i = t; i < Tp * 4; i += ATT_NT) {   // Tp*4 is a multiple of 128: whole waves stay together
         const int tok = i >> 2, c = i & 3;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, gv = qv, ov = qv;
         if (tok < T) {
@@ -330,16 +307,15 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
         dpart += __shfl_xor(dpart, 2, 64);
         if (c == 0) D_s[tok] = dpart;
     }
-    for (int i = t; i < Tp; i += 256) {
+    for (int i = t; i < Tp; i += ATT_NT) {
         vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
         lse_s[i] = i < T ? lse[bh * T + i] : 1e30f;    // rows past T: exp(S - 1e30) = 0
     }
     __syncthreads();
     const float inv_keep = 1.0f / (1.0f - p_drop);
-    const unsigned thr = (unsigned)ceilf(p_drop * 16777216.0f);
 
     // ---- phase A: queries on the lanes -> dQ^T[d, query] = K^T . dS^T
-    for (int qb = wave; qb < NB; qb += 4) {
+    for (int qb = wave; qb < NB; qb += ATT_NT / 64) {
         const int q = qb * 32 + li;
         const bf16x8 qh = row_frag(Qh, q, lh), gh = row_frag(Gh, q, lh);
         bf16x8 ql = qh, gl = gh;
@@ -361,9 +337,6 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
             const f32x16 S = mma<SPLIT>(kh, kl, qh, ql, zero16());    // S^T[key, query]
             const f32x16 dP = mma<SPLIT>(vh, vl, gh, gl, zero16());   // dP~^T[key, query]
             float ds[16];
-            const int ng = (T - kb * 32 + 7) >> 3;
-            unsigned keep = 0xFFFFu;
-            if (DROP) keep = keep_bits(seed, rbase + (uint64_t)(kb * 32), 1, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
@@ -373,7 +346,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
                         float ks = 1.f;
-                        if (DROP) ks = ((keep >> (4 * g + e)) & 1u) ? inv_keep : 0.f;
+                        if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
                     }
                 } else {
@@ -404,7 +377,7 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
     }
 
     // ---- phase B: keys on the lanes -> dV^T[d, key] = dO^T . P~ ; dK^T[d, key] = (Q scale)^T . dS
-    for (int kb = wave; kb < NB; kb += 4) {
+    for (int kb = wave; kb < NB; kb += ATT_NT / 64) {
         const int key = kb * 32 + li;
         const bf16x8 kh = row_frag(Kh, key, lh), vh = row_frag(Vh, key, lh);
         bf16x8 kl = kh, vl = vh;
@@ -425,9 +398,6 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
             const f32x16 S = mma<SPLIT>(qh, ql, kh, kl, zero16());    // S[query, key]
             const f32x16 dP = mma<SPLIT>(gh, gl, vh, vl, zero16());   // dP~[query, key]
             float pt[16], ds[16];
-            const int ng = (T - qb * 32 + 7) >> 3;
-            unsigned keep = 0xFFFFu;
-            if (DROP) keep = keep_bits(seed, (bh * T + (uint64_t)(qb * 32)) * T + (uint64_t)key, (uint64_t)T, lh, thr, ng);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int q0 = qb * 32 + 8 * g + 4 * lh;
@@ -437,7 +407,9 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const float p = kvalid ? __expf(S[4 * g + e] - l4[e]) : 0.f;
                         float ks = 1.f;
-                        if (DROP) ks = ((keep >> (4 * g + e)) & 1u) ? inv_keep : 0.f;
+                        if (DROP)
+                            ks = ac_rand01(seed, (bh * T + (uint64_t)(q0 + e)) * T + (uint64_t)key) >= p_drop
+                                     ? inv_keep : 0.f;
                         pt[4 * g + e] = p * ks;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - d4[e]);
                     }
@@ -489,7 +461,7 @@ int launch_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_fwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(256), lds, st, qkv, pad, out, lse, T,
+    hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT), lds, st, qkv, pad, out, lse, T,
                        H, p, seed);
     AC_CHECK_LAUNCH();
     return AC_OK;
@@ -503,7 +475,7 @@ int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_bwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(256), lds, st, dout, qkv, pad, out,
+    hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT), lds, st, dout, qkv, pad, out,
                        lse, dqkv, T, H, p, seed);
     AC_CHECK_LAUNCH();
     return AC_OK;
