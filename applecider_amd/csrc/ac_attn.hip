@@ -33,7 +33,11 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ATT_TMAX = 288;   // padded tokens per head (T <= 288)
-constexpr int ATT_NT = 512;     // 8 waves: T = 129 pads to 5 blocks of 32 tokens (4 waves would share them 2/1/1/1)
+// Threads per workgroup.  Backward: 8 waves — its ~200 registers per lane allow one workgroup per CU
+// either way, and T = 129 pads to 5 token blocks that 4 waves would share 2/1/1/1 (442 -> 325 us per
+// launch).  Forward: 4 waves — at ~140 registers three 4-wave workgroups fit a CU, which beats one
+// 8-wave workgroup (131 vs 171 us).
+constexpr int ATT_NT_FWD = 256, ATT_NT_BWD = 512;
 
 __device__ __forceinline__ unsigned short a_f2bf(float x) {
     return ac_f2h(x);
@@ -122,7 +126,7 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
 }
 
 template <bool SPLIT, bool DROP>
-__global__ __launch_bounds__(ATT_NT) void mha_fwd_mfma_kernel(const float *__restrict__ qkv,
+__global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *__restrict__ qkv,
                                                            const uint8_t *__restrict__ pad,
                                                            float *__restrict__ out, float *__restrict__ lse,
                                                            int T, int H, float p_drop, uint64_t seed) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_fwd_mfma_kernel(const float *__res
     const float *base = qkv + (int64_t)b * T * 3 * D + h * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
 
-    for (int i = t; i < Tp * 4; i += ATT_NT) {
+    for (int i = t; i < Tp * 4; i += ATT_NT_FWD) {
         const int tok = i >> 2, c = i & 3;
         f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
         if (tok < T) {
@@ -146,11 +150,11 @@ __global__ __launch_bounds__(ATT_NT) void mha_fwd_mfma_kernel(const float *__res
         img_store4<SPLIT>(Kh, Kl, tok, c, kv);
         img_store4<SPLIT>(Vh, Vl, tok, c, vv);
     }
-    for (int i = t; i < Tp; i += ATT_NT) vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
+    for (int i = t; i < Tp; i += ATT_NT_FWD) vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
     __syncthreads();
 
     const float inv_keep = 1.0f / (1.0f - p_drop);
-    for (int qb = wave; qb < NB; qb += ATT_NT / 64) {
+    for (int qb = wave; qb < NB; qb += ATT_NT_FWD / 64) {
         const int q = qb * 32 + li;
         float qv[8];
         {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_fwd_mfma_kernel(const float *__res
 }
 
 template <bool SPLIT, bool DROP>
-__global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
+__global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     const float *__restrict__ dout, const float *__restrict__ qkv, const uint8_t *__restrict__ pad,
     const float *__restrict__ out, const float *__restrict__ lse, float *__restrict__ dqkv, int T, int H,
     float p_drop, uint64_t seed) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     const uint64_t bh = (uint64_t)b * H + h;
 
-    for (int i = t; i < Tp * 4; i += ATT_NT) {   // Tp*4 is a multiple of 128: whole waves stay together
+    for (int i = t; i < Tp * 4; i += ATT_NT_BWD) {   // Tp*4 is a multiple of 128: whole waves stay together
         const int tok = i >> 2, c = i & 3;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, kv = qv, vv = qv, gv = qv, ov = qv;
         if (tok < T) {
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
         dpart += __shfl_xor(dpart, 2, 64);
         if (c == 0) D_s[tok] = dpart;
     }
-    for (int i = t; i < Tp; i += ATT_NT) {
+    for (int i = t; i < Tp; i += ATT_NT_BWD) {
         vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
         lse_s[i] = i < T ? lse[bh * T + i] : 1e30f;    // rows past T: exp(S - 1e30) = 0
     }
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
     const float inv_keep = 1.0f / (1.0f - p_drop);
 
     // ---- phase A: queries on the lanes -> dQ^T[d, query] = K^T . dS^T
-    for (int qb = wave; qb < NB; qb += ATT_NT / 64) {
+    for (int qb = wave; qb < NB; qb += ATT_NT_BWD / 64) {
         const int q = qb * 32 + li;
         const bf16x8 qh = row_frag(Qh, q, lh), gh = row_frag(Gh, q, lh);
         bf16x8 ql = qh, gl = gh;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(ATT_NT) void mha_bwd_mfma_kernel(
     }
 
     // ---- phase B: keys on the lanes -> dV^T[d, key] = dO^T . P~ ; dK^T[d, key] = (Q scale)^T . dS
-    for (int kb = wave; kb < NB; kb += ATT_NT / 64) {
+    for (int kb = wave; kb < NB; kb += ATT_NT_BWD / 64) {
         const int key = kb * 32 + li;
         const bf16x8 kh = row_frag(Kh, key, lh), vh = row_frag(Vh, key, lh);
         bf16x8 kl = kh, vl = vh;
@@ -461,7 +465,7 @@ int launch_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_fwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT), lds, st, qkv, pad, out, lse, T,
+    hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_FWD), lds, st, qkv, pad, out, lse, T,
                        H, p, seed);
     AC_CHECK_LAUNCH();
     return AC_OK;
@@ -475,7 +479,7 @@ int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_bwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT), lds, st, dout, qkv, pad, out,
+    hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_BWD), lds, st, dout, qkv, pad, out,
                        lse, dqkv, T, H, p, seed);
     AC_CHECK_LAUNCH();
     return AC_OK;
