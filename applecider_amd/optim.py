@@ -132,10 +132,61 @@ class FlatAdam:
         self.exp_avg = self.exp_avg_sq = None
 
     def _ensure(self):
+        old = None
+        if self.exp_avg is not None and self.step_count > 0 and not self.fp.is_current():
+            # the parameters were re-homed (model.to(), p.data reassigned) after training started:
+            # carry the moments over instead of silently restarting the optimizer
+            old = self._moments_per_param()
         if self.fp.ensure() or self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.fp.flat)
             self.exp_avg_sq = torch.zeros_like(self.fp.flat)
-            self.step_count = 0
+            if old is None:
+                self.step_count = 0
+            else:
+                self._load_moments(old)
+
+    def _moments_per_param(self):
+        out = []
+        for p, off in zip(self.fp.params, self.fp.offsets):
+            n = p.numel()
+            out.append((self.exp_avg[off:off + n].detach().clone().view(p.shape),
+                        self.exp_avg_sq[off:off + n].detach().clone().view(p.shape)))
+        return out
+
+    def _load_moments(self, moments):
+        for (m, v), p, off in zip(moments, self.fp.params, self.fp.offsets):
+            n = p.numel()
+            self.exp_avg[off:off + n].copy_(m.reshape(-1).to(self.exp_avg.device))
+            self.exp_avg_sq[off:off + n].copy_(v.reshape(-1).to(self.exp_avg.device))
+
+    def state_dict(self):
+        """torch.optim.Adam(W)-shaped state: {"state": {i: {"step", "exp_avg", "exp_avg_sq"}},
+        "param_groups": [{..., "params": [indices]}]} with per-parameter tensors (copies), so that a
+        checkpoint of the reference's optimizer and this one interchange."""
+        self._ensure()
+        state = {}
+        for i, (m, v) in enumerate(self._moments_per_param()):
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+        groups, i = [], 0
+        for g in self.param_groups:
+            n = len(g["params"])
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": list(range(i, i + n))})
+            i += n
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, lg in zip(self.param_groups, sd["param_groups"]):
+            if len(lg["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size "
+                                 "of optimizer's group")
+            g.update({k: v for k, v in lg.items() if k != "params"})
+        st = sd["state"]
+        if st:
+            self._load_moments([(st[i]["exp_avg"], st[i]["exp_avg_sq"]) for i in range(len(self.fp.params))])
+            self.step_count = int(float(st[0]["step"]))
 
     def prepare(self):
         """Flatten now (call after the model sits on its GPU; train_step does it lazily)."""
@@ -182,9 +233,34 @@ class FlatSGD:
         self.first = True
 
     def _ensure(self):
+        old = None
+        if self.buf is not None and not self.first and not self.fp.is_current():
+            old = [self.buf[off:off + p.numel()].detach().clone() for p, off in zip(self.fp.params, self.fp.offsets)]
         if self.fp.ensure() or self.buf is None:
             self.buf = torch.zeros_like(self.fp.flat)
-            self.first = True
+            if old is None:
+                self.first = True
+            else:   # parameters re-homed after training started: keep the momentum
+                for b, p, off in zip(old, self.fp.params, self.fp.offsets):
+                    self.buf[off:off + p.numel()].copy_(b.to(self.buf.device))
+
+    def state_dict(self):
+        """torch.optim.SGD-shaped state ({"state": {i: {"momentum_buffer"}}, "param_groups": [...]})."""
+        self._ensure()
+        state = {} if self.first else {
+            i: {"momentum_buffer": self.buf[off:off + p.numel()].detach().clone().view(p.shape)}
+            for i, (p, off) in enumerate(zip(self.fp.params, self.fp.offsets))}
+        g = self.param_groups[0]
+        return {"state": state, "param_groups": [{**{k: v for k, v in g.items() if k != "params"},
+                                                  "params": list(range(len(g["params"])))}]}
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items() if k != "params"})
+        if sd["state"]:
+            for i, (p, off) in enumerate(zip(self.fp.params, self.fp.offsets)):
+                self.buf[off:off + p.numel()].copy_(sd["state"][i]["momentum_buffer"].reshape(-1).to(self.buf.device))
+            self.first = False
 
     def prepare(self):
         self._ensure()

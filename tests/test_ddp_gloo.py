@@ -194,3 +194,47 @@ def test_bench_self_launch_dry_run():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     i = cmd.index(os.path.join(root, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+
+
+def test_flat_optimizer_state_dict_round_trip_and_rehoming():
+    """optimizer state can be checkpointed (torch.optim layout) and survives re-homing of
+    the parameters after training started.  Pure tensor logic: no kernel is launched."""
+    from applecider_amd.optim import FlatAdam, FlatSGD
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 64, 7)]
+    opt = FlatAdam([{"params": ps[:2], "lr": 1e-3}, {"params": ps[2:], "lr": 5e-4}])
+    opt.prepare()
+    opt.step_count = 3
+    opt.exp_avg.copy_(torch.arange(opt.exp_avg.numel(), dtype=torch.float32))
+    opt.exp_avg_sq.copy_(torch.arange(opt.exp_avg_sq.numel(), dtype=torch.float32) * 2)
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][1]["params"] == [2]
+    assert sd["state"][1]["exp_avg"].shape == (64,) and float(sd["state"][0]["step"]) == 3.0
+    # torch.optim.Adam accepts the same structure for the same parameters
+    ref = torch.optim.Adam([{"params": ps[:2]}, {"params": ps[2:]}])
+    ref.load_state_dict(sd)
+    assert torch.equal(ref.state[ps[1]]["exp_avg"], sd["state"][1]["exp_avg"])
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = FlatAdam([{"params": ps2[:2]}, {"params": ps2[2:]}])
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 3 and opt2.param_groups[1]["lr"] == 5e-4
+    assert all(torch.equal(a["exp_avg_sq"], b["exp_avg_sq"]) for a, b in
+               zip(opt2.state_dict()["state"].values(), sd["state"].values()))
+    # re-homing: p.data reassigned after training started -> moments carried over, step count kept
+    before = [m.clone() for m, _ in opt._moments_per_param()]
+    with torch.no_grad():
+        for p in ps:
+            p.data = p.data.clone()
+    assert not opt.fp.is_current()
+    opt._ensure()
+    assert opt.fp.is_current() and opt.step_count == 3
+    assert all(torch.equal(a, b) for a, (b, _) in zip(before, opt._moments_per_param()))
+    sgd = FlatSGD(ps, lr=0.01, momentum=0.9)
+    sgd.prepare()
+    assert sgd.state_dict()["state"] == {}
+    sgd.first = False
+    sgd.buf.fill_(1.5)
+    ssd = sgd.state_dict()
+    sgd2 = FlatSGD([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=0.1)
+    sgd2.load_state_dict(ssd)
+    assert not sgd2.first and sgd2.param_groups[0]["lr"] == 0.01
+    assert float(sgd2.buf[sgd2.fp.offsets[1]]) == 1.5
