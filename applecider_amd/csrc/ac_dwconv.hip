@@ -15,9 +15,14 @@ constexpr int CG = 32;  // channels per workgroup
 struct Geo {
     int H, W, C, nseg, Wp, np;  // nseg segments per row, padded pitch (pixels), padded plane pixels
 };
-template <int XS>
+// WC > 0: the plane is WC x WC at compile time (15 x 15 and 7 x 7, the ConvNeXt stages at 63 x 63
+// input), so every index division below is by a constant.  With run-time extents each thread spent
+// ~5000 instructions per sample on `q / Wp`, `q % Wp`, `p / W`, `it / nseg` (integer division is a
+// ~35-instruction sequence on gfx950): more than the 1400 FMAs of its share of the convolution.
+template <int XS, int WC = 0>
 __host__ __device__ inline Geo make_geo(int H, int W, int C) {
     Geo g;
+    if (WC > 0) H = W = WC;
     g.H = H;
     g.W = W;
     g.C = C;
@@ -55,6 +60,38 @@ __device__ __forceinline__ void load_padded_plane(float *plane, const float *src
     }
 }
 
+// The same with 16-byte global loads: 8 threads fetch the 32 channels of a pixel as one 128-byte
+// line, a wave covers 8 pixels per instruction (4x fewer load and LDS-store instructions), eight
+// independent lines in flight per thread.  Needs C % 4 == 0 and a 16-byte aligned plane.
+__device__ __forceinline__ void load_padded_plane_v4(float *plane, const float *src, const Geo &g, int cg0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int cq = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 32 pixel slots
+    const bool cv = cg0 + 4 * cq < g.C;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int q = slot; q < g.np; q += 32) {
+        const int yy = q / g.Wp - 3, xx = q % g.Wp - 3;
+        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) *(f32x4 *)(plane + q * CG + 4 * cq) = zero;
+    }
+    const int HW = g.H * g.W;
+    const float *sp = src + cg0 + 4 * cq;
+    for (int p0 = slot; p0 < HW; p0 += 256) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u;
+            v[u] = (cv && p < HW) ? *(const f32x4 *)(sp + (int64_t)p * g.C) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u;
+            if (p < HW) {
+                const int py = p / g.W, px = p - py * g.W;
+                *(f32x4 *)(plane + ((py + 3) * g.Wp + px + 3) * CG + 4 * cq) = v[u];
+            }
+        }
+    }
+}
+
 // out[o] += sum_{ky,kx} W(ky,kx) * plane[(y+ky), (x0+o+kx)] with W = taps (forward) or the taps
 // flipped on both axes (input gradient).  `pp` points at padded pixel (y, x0).
 template <int XS, bool FLIP>
@@ -74,20 +111,23 @@ __device__ __forceinline__ void conv_rows(const float *pp, int Wp, const float (
     }
 }
 
-template <int XS>
+template <int XS, int WC, bool V4>
 __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             const float *__restrict__ bias,
                                                             float *__restrict__ y, int H, int W,
                                                             int C) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
-    const Geo g = make_geo<XS>(H, W, C);
+    const Geo g = make_geo<XS, WC>(H, W, C);
     const int b = blockIdx.x, cg = blockIdx.y;
     const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const int cglob = cg * CG + c;
     const bool cvalid = cglob < C;
-    const int HW = H * W;
-    load_padded_plane(plane, x + (int64_t)b * HW * C, g, cglob, cvalid, c, ps);
+    const int HW = g.H * g.W;
+    if (V4)
+        load_padded_plane_v4(plane, x + (int64_t)b * HW * C, g, cg * CG);
+    else
+        load_padded_plane(plane, x + (int64_t)b * HW * C, g, cglob, cvalid, c, ps);
     float wt[49];
 #pragma unroll
     for (int k = 0; k < 49; ++k) wt[k] = cvalid ? w[k * C + cglob] : 0.f;
@@ -95,7 +135,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restr
     __syncthreads();
     if (!cvalid) return;
     float *yb = y + (int64_t)b * HW * C;
-    const int items = H * g.nseg;
+    const int items = g.H * g.nseg;
     for (int it = ps; it < items; it += 8) {
         const int py = it / g.nseg, x0 = (it % g.nseg) * XS;
         float out[XS];
@@ -104,7 +144,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restr
         conv_rows<XS, false>(plane + (py * g.Wp + x0) * CG + c, g.Wp, wt, out);
 #pragma unroll
         for (int o = 0; o < XS; ++o)
-            if (x0 + o < W) yb[(int64_t)(py * W + x0 + o) * C + cglob] = out[o];
+            if (x0 + o < g.W) yb[(int64_t)(py * g.W + x0 + o) * C + cglob] = out[o];
     }
 }
 
@@ -114,7 +154,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restr
 // The 49 dw partial sums (+ dbias) of the thread's channel stay in registers across the samples,
 // so the global atomics are 1/SPB of the per-sample count.
 constexpr int SPB = 4;
-template <int XS>
+template <int XS, int WC, bool V4>
 __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restrict__ dy,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w,
@@ -123,13 +163,14 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
                                                             float *__restrict__ dbias, int B, int H,
                                                             int W, int C) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
-    const Geo g = make_geo<XS>(H, W, C);
-    const int HW = H * W;
+    const Geo g = make_geo<XS, WC>(H, W, C);
+    const int HW = g.H * g.W;
+    W = g.W;
     const int cg = blockIdx.y;
     const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const int cglob = cg * CG + c;
     const bool cvalid = cglob < C;
-    const int items = H * g.nseg;
+    const int items = g.H * g.nseg;
     float wt[49], dwacc[49];
     float dbacc = 0.f;
 #pragma unroll
@@ -144,7 +185,10 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
         const float *dyb = dy + (int64_t)b * HW * C;
         float *dxb = dx + (int64_t)b * HW * C;
         __syncthreads();
-        load_padded_plane(plane, dyb, g, cglob, cvalid, c, ps);
+        if (V4)
+            load_padded_plane_v4(plane, dyb, g, cg * CG);
+        else
+            load_padded_plane(plane, dyb, g, cglob, cvalid, c, ps);
         __syncthreads();
         if (cvalid) {
             for (int it = ps; it < items; it += 8) {
@@ -159,7 +203,10 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
             }
         }
         __syncthreads();
-        load_padded_plane(plane, xb, g, cglob, cvalid, c, ps);
+        if (V4)
+            load_padded_plane_v4(plane, xb, g, cg * CG);
+        else
+            load_padded_plane(plane, xb, g, cglob, cvalid, c, ps);
         __syncthreads();
         if (cvalid) {
             for (int it = ps; it < items; it += 8) {
@@ -318,27 +365,35 @@ inline int small_spb(int B) {  // samples per workgroup: ~32 workgroups along th
     return spb < SM_SLOTS ? SM_SLOTS : spb;
 }
 
-template <int XS>
+template <int XS, int WC = 0>
 int launch_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W,
                int C, hipStream_t stream) {
-    const Geo g = make_geo<XS>(H, W, C);
+    const Geo g = make_geo<XS, WC>(H, W, C);
     const size_t lds = (size_t)g.np * CG * sizeof(float);
     if (lds > 65536) return AC_EINVAL;  // up to ~16x16 planes (ConvNeXt stage 0 is 15x15)
-    hipLaunchKernelGGL(dwconv7x7_fwd_kernel<XS>, dim3(B, (C + CG - 1) / CG), dim3(256), lds, stream,
-                       x, w, bias, y, H, W, C);
+    const dim3 grid(B, (C + CG - 1) / CG);
+    if (WC > 0 && C % 4 == 0 && ac_aligned16(x))
+        hipLaunchKernelGGL((dwconv7x7_fwd_kernel<XS, WC, true>), grid, dim3(256), lds, stream, x, w, bias, y, H, W, C);
+    else
+        hipLaunchKernelGGL((dwconv7x7_fwd_kernel<XS, WC, false>), grid, dim3(256), lds, stream, x, w, bias, y, H, W, C);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
-template <int XS>
+template <int XS, int WC = 0>
 int launch_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias,
                int B, int H, int W, int C, hipStream_t stream) {
-    const Geo g = make_geo<XS>(H, W, C);
+    const Geo g = make_geo<XS, WC>(H, W, C);
     const size_t planes = (size_t)g.np * CG * sizeof(float);
     const size_t red = (size_t)8 * 50 * CG * sizeof(float);
     const size_t lds = planes > red ? planes : red;
     if (lds > 65536) return AC_EINVAL;
-    hipLaunchKernelGGL(dwconv7x7_bwd_kernel<XS>, dim3((B + SPB - 1) / SPB, (C + CG - 1) / CG),
-                       dim3(256), lds, stream, dy, x, w, dx, dw, dbias, B, H, W, C);
+    const dim3 grid((B + SPB - 1) / SPB, (C + CG - 1) / CG);
+    if (WC > 0 && C % 4 == 0 && ac_aligned16(x) && ac_aligned16(dy))
+        hipLaunchKernelGGL((dwconv7x7_bwd_kernel<XS, WC, true>), grid, dim3(256), lds, stream, dy, x, w, dx, dw,
+                           dbias, B, H, W, C);
+    else
+        hipLaunchKernelGGL((dwconv7x7_bwd_kernel<XS, WC, false>), grid, dim3(256), lds, stream, dy, x, w, dx, dw,
+                           dbias, B, H, W, C);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -361,6 +416,8 @@ extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bia
     }
     if (W == 1) return launch_fwd<1>(x, w, bias, y, B, H, W, C, stream);
     if (W <= 3) return launch_fwd<3>(x, w, bias, y, B, H, W, C, stream);
+    if (H == 15 && W == 15) return launch_fwd<5, 15>(x, w, bias, y, B, H, W, C, stream);
+    if (H == 7 && W == 7) return launch_fwd<7, 7>(x, w, bias, y, B, H, W, C, stream);
     if (W == 7) return launch_fwd<7>(x, w, bias, y, B, H, W, C, stream);
     return launch_fwd<5>(x, w, bias, y, B, H, W, C, stream);
 }
@@ -382,6 +439,8 @@ extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w,
     }
     if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (H == 15 && W == 15) return launch_bwd<5, 15>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (H == 7 && W == 7) return launch_bwd<7, 7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     return launch_bwd<5>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
 }
