@@ -47,14 +47,14 @@ __device__ __forceinline__ void load_padded_plane(float *plane, const float *src
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + 8 * u;
-            v[u] = (cvalid && p < HW) ? src[(int64_t)p * g.C + cglob] : 0.f;
+            v[u] = src[(int64_t)(p < HW ? p : HW - 1) * g.C + (cvalid ? cglob : 0)];   // clamped, masked below
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + 8 * u;
             if (p < HW) {
                 const int py = p / g.W, px = p - py * g.W;
-                plane[((py + 3) * g.Wp + px + 3) * CG + c] = v[u];
+                plane[((py + 3) * g.Wp + px + 3) * CG + c] = cvalid ? v[u] : 0.f;
             }
         }
     }
@@ -73,20 +73,20 @@ __device__ __forceinline__ void load_padded_plane_v4(float *plane, const float *
         if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) *(f32x4 *)(plane + q * CG + 4 * cq) = zero;
     }
     const int HW = g.H * g.W;
-    const float *sp = src + cg0 + 4 * cq;
+    const float *sp = src + (cv ? cg0 + 4 * cq : 0);
     for (int p0 = slot; p0 < HW; p0 += 256) {
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + 32 * u;
-            v[u] = (cv && p < HW) ? *(const f32x4 *)(sp + (int64_t)p * g.C) : zero;
+            v[u] = *(const f32x4 *)(sp + (int64_t)(p < HW ? p : HW - 1) * g.C);   // clamped, masked below
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int p = p0 + 32 * u;
             if (p < HW) {
                 const int py = p / g.W, px = p - py * g.W;
-                *(f32x4 *)(plane + ((py + 3) * g.Wp + px + 3) * CG + 4 * cq) = v[u];
+                *(f32x4 *)(plane + ((py + 3) * g.Wp + px + 3) * CG + 4 * cq) = cv ? v[u] : zero;
             }
         }
     }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_fwd_kernel(const float *__restr
         load_padded_plane(plane, x + (int64_t)b * HW * C, g, cglob, cvalid, c, ps);
     float wt[49];
 #pragma unroll
-    for (int k = 0; k < 49; ++k) wt[k] = cvalid ? w[k * C + cglob] : 0.f;
+    for (int k = 0; k < 49; ++k) wt[k] = w[k * C + (cvalid ? cglob : 0)];
     const float bv = (cvalid && bias) ? bias[cglob] : 0.f;
     __syncthreads();
     if (!cvalid) return;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
     float dbacc = 0.f;
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
-        wt[k] = cvalid ? w[k * C + cglob] : 0.f;
+        wt[k] = w[k * C + (cvalid ? cglob : 0)];
         dwacc[k] = 0.f;
     }
     for (int s = 0; s < SPB; ++s) {
@@ -254,6 +254,195 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
                 atomicAdd(&dbias[cglob], s);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-row kernels for the square W x W planes of the benchmark geometry (W = 15, 7).  A thread owns
+// one channel and whole output ROWS, so the horizontal halo is known at compile time (taps that fall
+// outside a row are simply not multiplied) and the vertical halo is a per-row predicate: the LDS
+// plane is the bare [W][W][32 channels] image — 28.8 KB at 15 x 15 instead of 56 KB with halos, i.e.
+// five workgroups per CU instead of two, which is what this latency-bound kernel (HBM load ->
+// barrier -> LDS reads -> FMAs) lacked.  Per output row: 15 LDS reads feed up to 105 FMAs per tap row.
+// Planes are fetched with 16-byte loads (8 threads = the 32 channels of a pixel = one 128-byte line).
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void load_plane_rows(float *plane, const float *src, int C, int cg0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int HW = W * W, NIT = (HW + 31) / 32;
+    const int cq = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    const bool cv = cg0 + 4 * cq < C;
+    // unconditional loads from clamped addresses, masked when stored: a "load or zero" select makes
+    // hipcc branch around every load and wait for each in turn (cdna_hip_programming.md s.5 trap (c))
+    const float *sp = src + (cv ? cg0 + 4 * cq : 0);
+    f32x4 v[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int p = slot + 32 * u;
+        v[u] = *(const f32x4 *)(sp + (int64_t)(p < HW ? p : HW - 1) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int p = slot + 32 * u;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (p < HW) *(f32x4 *)(plane + p * CG + 4 * cq) = cv ? v[u] : zero;
+    }
+}
+
+// out[o] += sum_kx wrow[kx] * in[o + kx - 3] over the taps that stay inside the row (compile time)
+template <int W, bool FLIP>
+__device__ __forceinline__ void row_taps(const float (&in)[W], const float (&wt)[49], int ky, float (&out)[W]) {
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+        const float w = FLIP ? wt[(6 - ky) * 7 + (6 - kx)] : wt[ky * 7 + kx];
+#pragma unroll
+        for (int o = 0; o < W; ++o)
+            if (o + kx - 3 >= 0 && o + kx - 3 < W) out[o] = fmaf(w, in[o + kx - 3], out[o]);
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_rows_fwd_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ w,
+                                                              const float *__restrict__ bias,
+                                                              float *__restrict__ y, int C) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    constexpr int HW = W * W;
+    const int b = blockIdx.x, cg = blockIdx.y;
+    const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
+    const int cglob = cg * CG + c;
+    const bool cvalid = cglob < C;
+    load_plane_rows<W>(plane, x + (int64_t)b * HW * C, C, cg * CG);
+    float wt[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) wt[k] = w[k * C + (cvalid ? cglob : 0)];
+    const float bv = (cvalid && bias) ? bias[cglob] : 0.f;
+    __syncthreads();
+    if (!cvalid) return;
+    float *yb = y + (int64_t)b * HW * C + cglob;
+    for (int py = ps; py < W; py += 8) {
+        float out[W];
+#pragma unroll
+        for (int o = 0; o < W; ++o) out[o] = bv;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = py + ky - 3;
+            if (yy >= 0 && yy < W) {
+                float in[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) in[j] = plane[(yy * W + j) * CG + c];
+                row_taps<W, false>(in, wt, ky, out);
+            }
+            // keep the LDS reads of the next tap row behind this row's FMAs: hoisted together, the seven
+            // rows need 105 registers of inputs and the kernel drops to two waves per SIMD
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int o = 0; o < W; ++o) yb[(int64_t)(py * W + o) * C] = out[o];
+    }
+}
+
+// Backward: both planes (dy, x) of a sample in LDS; per output row the thread forms dx (correlation of
+// dy with the flipped taps) and adds its share of dw / dbias; the 49 + 1 partial sums stay in
+// registers over the SPB samples of the workgroup and are reduced through LDS at the end.
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_rows_bwd_kernel(const float *__restrict__ dy,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ w,
+                                                              float *__restrict__ dx, float *__restrict__ dw,
+                                                              float *__restrict__ dbias, int B, int C) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    constexpr int HW = W * W;
+    float *pdy = plane, *px = plane + HW * CG;
+    const int cg = blockIdx.y;
+    const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
+    const int cglob = cg * CG + c;
+    const bool cvalid = cglob < C;
+    float wt[49], dwacc[49];
+    float dbacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+        wt[k] = w[k * C + (cvalid ? cglob : 0)];
+        dwacc[k] = 0.f;
+    }
+    for (int s = 0; s < SPB; ++s) {
+        const int b = blockIdx.x * SPB + s;
+        if (b >= B) break;
+        __syncthreads();
+        load_plane_rows<W>(pdy, dy + (int64_t)b * HW * C, C, cg * CG);
+        load_plane_rows<W>(px, x + (int64_t)b * HW * C, C, cg * CG);
+        __syncthreads();
+        if (cvalid) {
+            float *dxb = dx + (int64_t)b * HW * C + cglob;
+            for (int py = ps; py < W; py += 8) {
+                float out[W], d[W];
+#pragma unroll
+                for (int o = 0; o < W; ++o) {
+                    out[o] = 0.f;
+                    d[o] = pdy[(py * W + o) * CG + c];
+                    dbacc += d[o];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    const int yy = py + ky - 3;
+                    if (yy >= 0 && yy < W) {
+                        float in[W];
+#pragma unroll
+                        for (int j = 0; j < W; ++j) in[j] = pdy[(yy * W + j) * CG + c];
+                        row_taps<W, true>(in, wt, ky, out);
+#pragma unroll
+                        for (int j = 0; j < W; ++j) in[j] = px[(yy * W + j) * CG + c];
+#pragma unroll
+                        for (int kx = 0; kx < 7; ++kx) {
+                            float a = dwacc[ky * 7 + kx];
+#pragma unroll
+                            for (int o = 0; o < W; ++o)
+                                if (o + kx - 3 >= 0 && o + kx - 3 < W) a = fmaf(d[o], in[o + kx - 3], a);
+                            dwacc[ky * 7 + kx] = a;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < W; ++o) dxb[(int64_t)(py * W + o) * C] = out[o];
+            }
+        }
+    }
+    __syncthreads();
+    float *red = plane;  // [8][50][32] floats = 51.2 KB
+    if (cvalid) {
+#pragma unroll
+        for (int k = 0; k < 49; ++k) red[(ps * 50 + k) * CG + c] = dwacc[k];
+        red[(ps * 50 + 49) * CG + c] = dbacc;
+    }
+    __syncthreads();
+    if (cvalid) {
+        for (int k = ps; k < 50; k += 8) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[(q * 50 + k) * CG + c];
+            if (k < 49)
+                atomicAdd(&dw[k * C + cglob], sum);
+            else if (dbias)
+                atomicAdd(&dbias[cglob], sum);
+        }
+    }
+}
+
+template <int W>
+int launch_rows_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C, hipStream_t stream) {
+    const size_t lds = (size_t)W * W * CG * sizeof(float);
+    hipLaunchKernelGGL(dwconv_rows_fwd_kernel<W>, dim3(B, (C + CG - 1) / CG), dim3(256), lds, stream, x, w, bias, y, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+template <int W>
+int launch_rows_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias, int B,
+                    int C, hipStream_t stream) {
+    const size_t planes = (size_t)2 * W * W * CG * sizeof(float), red = (size_t)8 * 50 * CG * sizeof(float);
+    const size_t lds = planes > red ? planes : red;
+    hipLaunchKernelGGL(dwconv_rows_bwd_kernel<W>, dim3((B + SPB - 1) / SPB, (C + CG - 1) / CG), dim3(256), lds,
+                       stream, dy, x, w, dx, dw, dbias, B, C);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +605,8 @@ extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bia
     }
     if (W == 1) return launch_fwd<1>(x, w, bias, y, B, H, W, C, stream);
     if (W <= 3) return launch_fwd<3>(x, w, bias, y, B, H, W, C, stream);
+    if (H == W && (W == 15 || W == 7) && C % 4 == 0 && ac_aligned16(x))
+        return W == 15 ? launch_rows_fwd<15>(x, w, bias, y, B, C, stream) : launch_rows_fwd<7>(x, w, bias, y, B, C, stream);
     if (H == 15 && W == 15) return launch_fwd<5, 15>(x, w, bias, y, B, H, W, C, stream);
     if (H == 7 && W == 7) return launch_fwd<7, 7>(x, w, bias, y, B, H, W, C, stream);
     if (W == 7) return launch_fwd<7>(x, w, bias, y, B, H, W, C, stream);
@@ -439,6 +630,9 @@ extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w,
     }
     if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (H == W && (W == 15 || W == 7) && C % 4 == 0 && ac_aligned16(x) && ac_aligned16(dy))
+        return W == 15 ? launch_rows_bwd<15>(dy, x, w, dx, dw, dbias, B, C, stream)
+                       : launch_rows_bwd<7>(dy, x, w, dx, dw, dbias, B, C, stream);
     if (H == 15 && W == 15) return launch_bwd<5, 15>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (H == 7 && W == 7) return launch_bwd<7, 7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
     if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
