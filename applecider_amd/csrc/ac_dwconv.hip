@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__re
     for (int ty = 0; ty < T; ++ty)
 #pragma unroll
         for (int tx = 0; tx < T; ++tx) {
-            wt[ty * T + tx] = cv ? w[((ty + 4 - S) * 7 + (tx + 4 - S)) * C + c] : 0.f;
+            wt[ty * T + tx] = w[((ty + 4 - S) * 7 + (tx + 4 - S)) * C + (cv ? c : 0)];   // unconditional (clamped) load
             dwa[ty * T + tx] = 0.f;
         }
     const int b1 = min(B, (int)(blockIdx.y + 1) * spb);

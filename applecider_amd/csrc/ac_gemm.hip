@@ -185,7 +185,9 @@ enum : unsigned {
     X(11, E_C16 | E_BIAS | E_GELU) X(12, E_C32 | E_BIAS | E_CSCALE | E_RES) X(13, E_C32 | E_BIAS | E_GELU) \
     X(14, E_C16 | E_BIAS | E_GELU | E_PRE | E_FAST) X(15, E_C16 | E_DGELU | E_FAST)               \
     X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)     \
-    X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF) X(21, E_C16 | E_BIAS | E_GOFF)
+    X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF) X(21, E_C16 | E_BIAS | E_GOFF)                    \
+    X(22, E_C32 | E_BIAS | E_GELU | E_PRE) X(23, E_C32 | E_BIAS | E_RELU)                                 \
+    X(24, E_C32 | E_BIAS | E_RELU | E_PRE | E_RES) X(25, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES)
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
