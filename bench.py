@@ -451,7 +451,12 @@ def main():
             a, pk, unit = cls["flops"] / sec / 1e12, peak, "TFLOP/s"
         else:
             a, pk, unit = cls["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        return {"bound": bound, "achieved": round(a, 2), "peak": pk, "unit": unit, "frac": round(a / pk, 4),
+        extra = {}
+        if bound == "mfma":
+            # what the matrix cores EXECUTE (bf16x3: three MFMAs per algorithmic product) against the dense peak
+            ex = a * MFMA_ISSUE_FACTOR[args.math]
+            extra = {"executed_tflops": round(ex, 2), "mfma_util": round(ex / pk, 4)}
+        return {"bound": bound, "achieved": round(a, 2), "peak": pk, "unit": unit, "frac": round(a / pk, 4), **extra,
                 "traffic": None, "kernel": kname, "launches": cls["launches"],
                 "avg_launch_ms": round(cls["ms"] / cls["launches"], 4),
                 "ms_per_step": round(cls["ms"] / args.steps, 3),
