@@ -17,6 +17,9 @@
 // tile costs one MFMA, which is cheaper than carrying and rescaling an output accumulator.
 // Backward is two phases (queries on the lanes for dQ, keys on the lanes for dK / dV), each
 // recomputing P from the saved log-sum-exp; D_i = sum_d dO_id O_id is formed while staging.
+// (Measured alternative, dropped: ONE phase with the keys on the lanes, dS crossing a per-wave LDS
+// transpose for dQ = dS . K and the partial dQ tiles summed with ds_add_f32 — half the exp / dropout work
+// per head, but 447 us per launch against 325 us for the two-phase form at B = 512, T = 129.)
 //
 // SPLIT = false: bf16 operands (math mode 'bf16').  SPLIT = true: every operand is split into
 // hi + lo bf16 halves and every product is 3 MFMAs (math mode 'bf16x3', ~2^-16 per product); the
@@ -270,63 +273,17 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
     }
 }
 
-// MFMA operand "column of the image" in the STANDARD k order (element j of lane half h = token
-// rbase + j, rbase = block*32 + 16*s + 8*h): the partner operand comes from memory (frag_tq below), not
-// from an accumulator tile.
-__device__ __forceinline__ bf16x8 col_frag_std(const unsigned short *img, int rbase, int lane) {
-    const int i = lane & 15, q = i >> 2, p = i & 3;
-    const int r0 = rbase + q, r1 = r0 + 4;
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_v4 *)(img + r0 * 16 + 8 * ((p >> 1) ^ ((r0 >> 3) & 1)) + 4 * (p & 1)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_v4 *)(img + r1 * 16 + 8 * ((p >> 1) ^ ((r1 >> 3) & 1)) + 4 * (p & 1)));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-// A operand (row = query lane & 31, k = 8 consecutive keys) from the per-wave transpose image
-// T[key][32 queries] (64-byte rows: the four rows of a transposed 4x16 block start 16 banks apart and the
-// two blocks of a half-wave 8 banks apart: conflict free without padding)
-__device__ __forceinline__ bf16x8 frag_tq(const unsigned short *img, int s, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int k0 = 16 * s + 8 * (g >> 1);
-    const unsigned short *a0 = img + (k0 + q) * 32 + 16 * (g & 1) + 4 * pp;
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * 32));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-// Backward, one pass: a wave owns a block of 32 KEYS (keys on the lanes) and walks the query blocks.
-// Per 32x32 tile: S = (Q scale) K^T and dP~ = dO V^T (one MFMA each), P = exp(S - lse), dropout,
-// dS = P (k dP~ - D) — ONCE per tile —, then
-//   dV^T += dO^T . P~ ,  dK^T += (Q scale)^T . dS        (P~ / dS straight from the registers: A . X form)
-//   dQ   += dS . K : the contraction runs over the LANE index of dS, so the tile crosses a 2 KB
-//           per-wave LDS image once ([key][query], packed 8-byte stores, transposed reads) and the
-//           32 x 16 result is added into a workgroup-wide fp32 dQ buffer in LDS (ds_add_f32), because
-//           the key blocks of one query live in different waves.
-// (The first version recomputed every tile in a second, query-on-the-lanes phase for dQ: twice the
-// exp + dropout-hash work, which is what this kernel's time consists of.)
 template <bool SPLIT, bool DROP>
 __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     const float *__restrict__ dout, const float *__restrict__ qkv, const uint8_t *__restrict__ pad,
     const float *__restrict__ out, const float *__restrict__ lse, float *__restrict__ dqkv, int T, int H,
     float p_drop, uint64_t seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
-    constexpr int NW = ATT_NT_BWD / 64, TIMG = 32 * 32;
     const int Tp = (T + 31) & ~31, NB = Tp >> 5, IMG = Tp * 16;
     unsigned short *Qh = smh, *Kh = Qh + IMG, *Vh = Kh + IMG, *Gh = Vh + IMG;   // G = dO
     unsigned short *Ql = Gh + IMG, *Kl = Ql + (SPLIT ? IMG : 0), *Vl = Kl + (SPLIT ? IMG : 0),
                    *Gl = Vl + (SPLIT ? IMG : 0);
-    unsigned short *tr_all = smh + (SPLIT ? 8 : 4) * IMG;                       // per-wave transpose images
-    float *dq_s = (float *)(tr_all + NW * (SPLIT ? 2 : 1) * TIMG);               // [Tp][16] fp32
-    float *lse_s = dq_s + Tp * 16;
+    float *lse_s = (float *)(smh + (SPLIT ? 8 : 4) * IMG);
     float *D_s = lse_s + Tp;
     uint8_t *vm8 = (uint8_t *)(D_s + Tp);
     const int wg = xcd_order(blockIdx.x, gridDim.x);
@@ -337,7 +294,6 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     float *dbase = dqkv + (int64_t)b * T * 3 * D + h * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     const uint64_t bh = (uint64_t)b * H + h;
-    unsigned short *trh = tr_all + wave * (SPLIT ? 2 : 1) * TIMG, *trl = trh + TIMG;
 
     for (int i = t; i < Tp * 4; i += ATT_NT_BWD) {   // Tp*4 is a multiple of 128: whole waves stay together
         const int tok = i >> 2, c = i & 3;
@@ -357,7 +313,6 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
         dpart += __shfl_xor(dpart, 1, 64);
         dpart += __shfl_xor(dpart, 2, 64);
         if (c == 0) D_s[tok] = dpart;
-        *(f32x4 *)(dq_s + tok * 16 + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int i = t; i < Tp; i += ATT_NT_BWD) {
         vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
@@ -366,21 +321,76 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     __syncthreads();
     const float inv_keep = 1.0f / (1.0f - p_drop);
 
-    for (int kb = wave; kb < NB; kb += NW) {
+    // ---- phase A: queries on the lanes -> dQ^T[d, query] = K^T . dS^T
+    for (int qb = wave; qb < NB; qb += ATT_NT_BWD / 64) {
+        const int q = qb * 32 + li;
+        const bf16x8 qh = row_frag(Qh, q, lh), gh = row_frag(Gh, q, lh);
+        bf16x8 ql = qh, gl = gh;
+        if (SPLIT) {
+            ql = row_frag(Ql, q, lh);
+            gl = row_frag(Gl, q, lh);
+        }
+        const float lse_q = lse_s[q], D_q = D_s[q];
+        const uint64_t rbase = (bh * T + (uint64_t)q) * T;
+        f32x16 dQ = zero16();
+        for (int kb = 0; kb < NB; ++kb) {
+            const int krow = kb * 32 + li;
+            const bf16x8 kh = row_frag(Kh, krow, lh), vh = row_frag(Vh, krow, lh);
+            bf16x8 kl = kh, vl = vh;
+            if (SPLIT) {
+                kl = row_frag(Kl, krow, lh);
+                vl = row_frag(Vl, krow, lh);
+            }
+            const f32x16 S = mma<SPLIT>(kh, kl, qh, ql, zero16());    // S^T[key, query]
+            const f32x16 dP = mma<SPLIT>(vh, vl, gh, gl, zero16());   // dP~^T[key, query]
+            float ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = kb * 32 + 8 * g + 4 * lh;
+                if (kb * 32 + 8 * g < T) {
+                    const unsigned w = *(const unsigned *)(vm8 + key0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
+                        float ks = 1.f;
+                        if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
+                        ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds[4 * g + e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = ds[8 * s + j];
+                bf16x8 xh, xl;
+                cvt8<SPLIT>(x, xh, xl);
+                const int rb = kb * 32 + 16 * s + 4 * lh;
+                const bf16x8 kth = col_frag(Kh, rb, lane);
+                bf16x8 ktl = kth;
+                if (SPLIT) ktl = col_frag(Kl, rb, lane);
+                dQ = mma<SPLIT>(kth, ktl, xh, xl, dQ);   // A . X: rows d, lanes query
+            }
+        }
+        if (q < T) {
+            float *dq = dbase + (int64_t)q * 3 * D + 4 * lh;
+            f32x4 a = {dQ[0], dQ[1], dQ[2], dQ[3]}, c = {dQ[4], dQ[5], dQ[6], dQ[7]};
+            *(f32x4 *)dq = a * 0.25f;
+            *(f32x4 *)(dq + 8) = c * 0.25f;
+        }
+    }
+
+    // ---- phase B: keys on the lanes -> dV^T[d, key] = dO^T . P~ ; dK^T[d, key] = (Q scale)^T . dS
+    for (int kb = wave; kb < NB; kb += ATT_NT_BWD / 64) {
         const int key = kb * 32 + li;
         const bf16x8 kh = row_frag(Kh, key, lh), vh = row_frag(Vh, key, lh);
         bf16x8 kl = kh, vl = vh;
         if (SPLIT) {
             kl = row_frag(Kl, key, lh);
             vl = row_frag(Vl, key, lh);
-        }
-        // B operand of dQ = dS . K: K[key k][d], standard k order (hoisted: the same for every query block)
-        bf16x8 kbh[2], kbl[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            kbh[s] = col_frag_std(Kh, kb * 32 + 16 * s + 8 * lh, lane);
-            kbl[s] = kbh[s];
-            if (SPLIT) kbl[s] = col_frag_std(Kl, kb * 32 + 16 * s + 8 * lh, lane);
         }
         const bool kvalid = vm8[key] != 0;
         f32x16 dV = zero16(), dK = zero16();
@@ -415,20 +425,6 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
                     for (int e = 0; e < 4; ++e) pt[4 * g + e] = ds[4 * g + e] = 0.f;
                 }
             }
-            // dS tile -> per-wave image T[key][query] (lane = key row; 4 consecutive queries = 8 bytes)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                s16x4 wh, wl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned short hb = a_f2bf(ds[4 * g + e]);
-                    wh[e] = (short)hb;
-                    if (SPLIT) wl[e] = (short)a_f2bf(ds[4 * g + e] - a_bf2f(hb));
-                }
-                *(s16x4 *)(trh + li * 32 + 8 * g + 4 * lh) = wh;
-                if (SPLIT) *(s16x4 *)(trl + li * 32 + 8 * g + 4 * lh) = wl;
-            }
-            __builtin_amdgcn_wave_barrier();   // cross-lane hand-over through LDS: keep stores above the reads
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float x[8], y[8];
@@ -450,24 +446,6 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
                 dV = mma<SPLIT>(gth, gtl, xh, xl, dV);
                 dK = mma<SPLIT>(qth, qtl, yh, yl, dK);
             }
-            // dQ tile [32 queries x 16 d] = dS . K through the transposed image (the wave's own LDS writes
-            // are ordered before its reads by the lgkmcnt wait the compiler places; no other wave touches it)
-            f32x16 dQ = zero16();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 ah = frag_tq(trh, s, lane);
-                bf16x8 al = ah;
-                if (SPLIT) al = frag_tq(trl, s, lane);
-                dQ = mma<SPLIT>(ah, al, kbh[s], kbl[s], dQ);
-            }
-            __builtin_amdgcn_wave_barrier();   // ... and the next tile's stores below these reads
-            if (li < 16) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int qq = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    atomicAdd(dq_s + qq * 16 + li, dQ[e]);
-                }
-            }
         }
         if (key < T) {
             float *dk = dbase + (int64_t)key * 3 * D + D + 4 * lh;
@@ -479,11 +457,6 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
             *(f32x4 *)dv = e;
             *(f32x4 *)(dv + 8) = f;
         }
-    }
-    __syncthreads();
-    for (int i = t; i < T * 4; i += ATT_NT_BWD) {
-        const int tok = i >> 2, c = i & 3;
-        *(f32x4 *)(dbase + (int64_t)tok * 3 * D + 4 * c) = *(const f32x4 *)(dq_s + tok * 16 + 4 * c) * 0.25f;
     }
 }
 
@@ -505,11 +478,9 @@ template <bool SPLIT, bool DROP>
 int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const float *out, const float *lse,
                float *dqkv, int B, int T, int H, float p, uint64_t seed, hipStream_t st) {
     const int Tp = (T + 31) & ~31;
-    const size_t lds = (size_t)(SPLIT ? 8 : 4) * Tp * 32                                     // operand images
-                       + (size_t)(ATT_NT_BWD / 64) * (SPLIT ? 2 : 1) * 32 * 32 * sizeof(short)  // transposes
-                       + (size_t)Tp * 16 * sizeof(float) + 2 * Tp * sizeof(float) + Tp;         // dQ, lse, D, mask
+    const size_t lds = (size_t)(SPLIT ? 8 : 4) * Tp * 32 + 2 * Tp * sizeof(float) + Tp;
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_bwd_mfma_kernel<SPLIT, DROP>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
     hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_BWD), lds, st, dout, qkv, pad, out,
                        lse, dqkv, T, H, p, seed);

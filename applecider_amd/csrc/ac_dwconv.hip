@@ -301,7 +301,7 @@ __device__ __forceinline__ void row_taps(const float (&in)[W], const float (&wt)
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void dwconv_rows_fwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(256, 3) void dwconv_rows_fwd_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ w,
                                                               const float *__restrict__ bias,
                                                               float *__restrict__ y, int C) {
@@ -313,12 +313,19 @@ __global__ __launch_bounds__(256) void dwconv_rows_fwd_kernel(const float *__res
     const bool cvalid = cglob < C;
     load_plane_rows<W>(plane, x + (int64_t)b * HW * C, C, cg * CG);
     float wt[49];
+    {
+        const float *wp = w + (cvalid ? cglob : 0);   // running address (49 separate ones cost 98 registers)
 #pragma unroll
-    for (int k = 0; k < 49; ++k) wt[k] = w[k * C + (cvalid ? cglob : 0)];
+        for (int k = 0; k < 49; ++k) {
+            wt[k] = *wp;
+            wp += C;
+        }
+    }
     const float bv = (cvalid && bias) ? bias[cglob] : 0.f;
     __syncthreads();
     if (!cvalid) return;
     float *yb = y + (int64_t)b * HW * C + cglob;
+#pragma unroll 1
     for (int py = ps; py < W; py += 8) {
         float out[W];
 #pragma unroll
@@ -336,8 +343,12 @@ __global__ __launch_bounds__(256) void dwconv_rows_fwd_kernel(const float *__res
             // rows need 105 registers of inputs and the kernel drops to two waves per SIMD
             __builtin_amdgcn_sched_barrier(0);
         }
+        float *yp = yb + (int64_t)py * W * C;   // one running address: W separate 64-bit addresses cost 2W registers
 #pragma unroll
-        for (int o = 0; o < W; ++o) yb[(int64_t)(py * W + o) * C] = out[o];
+        for (int o = 0; o < W; ++o) {
+            *yp = out[o];
+            yp += C;
+        }
     }
 }
 
