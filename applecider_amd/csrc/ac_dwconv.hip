@@ -301,7 +301,7 @@ __device__ __forceinline__ void row_taps(const float (&in)[W], const float (&wt)
 }
 
 template <int W>
-__global__ __launch_bounds__(256, 3) void dwconv_rows_fwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(256) void dwconv_rows_fwd_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ w,
                                                               const float *__restrict__ bias,
                                                               float *__restrict__ y, int C) {
