@@ -487,7 +487,7 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *win_h = reinterpret_cast<unsigned short *>(smem);
     const ac_convwin_desc &d = p.d;
-    const int Wrows = BM + TC - 1;
+    const int Wrows = (d.L < BM ? (BM / d.L) * (d.L + TC - 1) : BM + TC - 1);
     unsigned short *win_l = win_h + Wrows * CC;
     unsigned short *bst = win_l + Wrows * CC;  // 2 stages x (hi tile | lo tile)
 
@@ -499,9 +499,12 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
     const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int tn = wg % p.tiles_n;
-    const int tl = (wg / p.tiles_n) % p.tiles_l;
-    const int b = wg / (p.tiles_n * p.tiles_l);
-    const int l0 = tl * BM;
+    // A tile is BM consecutive rows of the [B*L] output.  L >= BM: a slice of one sample.  L < BM
+    // (SpectraNet stages 4-5, L = 64 / 16): BM / L whole samples, each with its own zero-padded window.
+    const int R0 = (wg / p.tiles_n) * BM;
+    const int b = R0 / d.L, l0 = R0 - b * d.L;
+    const int Ls = d.L < BM ? d.L : BM, spt = BM / Ls;   // rows per sample in the tile, samples per tile
+    const int lsh = 31 - __builtin_clz(Ls);               // Ls is a power of two when spt > 1
 
     const unsigned short *aptr = (const unsigned short *)d.a + (int64_t)b * d.a_batch_stride +
                                  (int64_t)(d.row_base + l0) * d.a_row_stride + d.a_col_off;
@@ -527,14 +530,15 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
         for (int t0 = 0; t0 < d.k; t0 += TC) {
             const int tc = (d.k - t0) < TC ? (d.k - t0) : TC;   // taps in this chunk (K tiles: one per tap)
             __syncthreads();   // every wave is done with the previous chunk's window and weight stages
+            const int wr = Ls + tc - 1;   // window rows of one sample
             {
-                const int rows = BM + tc - 1;
                 const unsigned short *a = aptr + (int64_t)t0 * d.a_row_stride + cch * CC;
-                for (int idx = t; idx < rows * 8; idx += NT) {
-                    const int r = idx >> 3, cc = idx & 7;
-                    const unsigned short *src = a + (int64_t)r * d.a_row_stride + cc * 8;
-                    *(u32x4 *)(win_h + win_off<64>(r, cc)) = ac_gload<u32x4>(src);
-                    *(u32x4 *)(win_l + win_off<64>(r, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
+                for (int idx = t; idx < spt * wr * 8; idx += NT) {
+                    const int rr = idx >> 3, cc = idx & 7;
+                    const int sidx = spt > 1 ? rr / wr : 0, r = rr - sidx * wr;
+                    const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
+                    *(u32x4 *)(win_h + win_off<64>(rr, cc)) = ac_gload<u32x4>(src);
+                    *(u32x4 *)(win_l + win_off<64>(rr, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
                 }
             }
             auto wload = [&](int kt, u32x4 (&v)[2 * BCH]) {
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                 }
             };
             auto compute = [&](int kt, const unsigned short *bt) {
-                const int r0 = wm * 64 + li + kt, r1 = r0 + 32;
+                const int m0 = wm * 64 + li, m1 = m0 + 32;   // tile rows -> (sample, position) -> window rows
+                const int r0 = (m0 >> lsh) * wr + (m0 & (Ls - 1)) + kt, r1 = (m1 >> lsh) * wr + (m1 & (Ls - 1)) + kt;
                 const int n0 = wn * 64 + li, n1 = n0 + 32;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -606,8 +611,8 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     }
     __syncthreads();
 
-    // ---- epilogue (fp32 output only): out[b, l0 + m, n] (+)= acc (+ bias), 16-byte stores through LDS
-    float *cb = d.c + ((int64_t)b * d.L + l0) * d.ldc;
+    // ---- epilogue (fp32 output only): out[R0 + m, n] (+)= acc (+ bias), 16-byte stores through LDS
+    float *cb = d.c + (int64_t)R0 * d.ldc;
     float *wbuf = smem + wave * 2048;
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = tn * BN + wn * 64 + c4;
@@ -642,10 +647,11 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
     const ac_convwin_desc &d = p.d;
     const size_t stages = (size_t)2 * 2 * BN * 64 * sizeof(short);
     const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
-    int TC = rows_budget - BM + 1;
+    const int spt = d.L < BM ? BM / d.L : 1, Ls = d.L < BM ? d.L : BM;
+    int TC = rows_budget / spt - Ls + 1;
     if (TC < 1) return AC_EINVAL;
     if (TC > d.k) TC = d.k;
-    const size_t lds = (size_t)(BM + TC - 1) * 64 * 2 * sizeof(short) + stages;
+    const size_t lds = (size_t)spt * (Ls + TC - 1) * 64 * 2 * sizeof(short) + stages;
     if (lds < (size_t)WM * WN * 8192) return AC_EINVAL;   // the epilogue parks 8 KB per wave
     p.tiles_l = d.L / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
@@ -658,8 +664,8 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
-    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN>), dim3(d.B * p.tiles_l * p.tiles_n), dim3(NT), lds, stream,
-                       p, TC);
+    const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
+    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -694,7 +700,9 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
     const ac_convwin_desc &d = p.d;
     if (!d.a || !d.w || !d.c || d.c16 || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.N <= 0) return AC_EINVAL;
     if (d.a_lo_off == 0 || d.w_lo_off == 0) return AC_EINVAL;
-    if (d.C <= 0 || (d.C % 64) || (d.L % 128)) return AC_EINVAL;
+    // L a multiple of the 128 / 256-row tile, or a power of two below it (whole samples per 256-row tile)
+    const bool short_seq = d.L < 128 && d.L >= 8 && (d.L & (d.L - 1)) == 0 && (((int64_t)d.B * d.L) % 256) == 0;
+    if (d.C <= 0 || (d.C % 64) || ((d.L % 128) && !short_seq)) return AC_EINVAL;
     if (!ac_aligned16(d.a) || !ac_aligned16(d.w) || !ac_aligned16(d.c)) return AC_EALIGN;
     if ((d.a_row_stride % 8) || (d.a_batch_stride % 8) || (d.a_col_off % 8) || (d.w_row_stride % 8) ||
         (d.w_tap_stride % 8) || (d.a_lo_off % 8) || (d.w_lo_off % 8) || (d.N % 4) || (d.ldc % 4) ||
@@ -702,7 +710,7 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
         return AC_EALIGN;
     hipStream_t stream = (hipStream_t)stream_;
     const bool wide = d.N > 64;
-    if (d.L % 256 == 0) return wide ? launch_x3<4, 2>(p, stream) : launch_x3<4, 1>(p, stream);
+    if (d.L % 256 == 0 || short_seq) return wide ? launch_x3<4, 2>(p, stream) : launch_x3<4, 1>(p, stream);
     return wide ? launch_x3<2, 2>(p, stream) : launch_x3<2, 1>(p, stream);
 }
 

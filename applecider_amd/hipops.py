@@ -241,7 +241,8 @@ def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, 
     planes — hi*hi (+bias), lo*hi, hi*lo — accumulating in the fp32 output.  False when the shape is
     not covered (nothing has been written then)."""
     (ah, al), (wh, wl) = a_planes, w_planes
-    if _CONVWIN and _CONVWIN_X3_FUSED and Cw % 64 == 0 and L % 128 == 0 and N % 4 == 0:
+    short_seq = L < 128 and L >= 8 and (L & (L - 1)) == 0 and (B * L) % 256 == 0   # whole samples per 256-row tile
+    if _CONVWIN and _CONVWIN_X3_FUSED and Cw % 64 == 0 and (L % 128 == 0 or short_seq) and N % 4 == 0:
         # one launch: both planes of the window in LDS (chunked over channels / taps), 3 MFMAs per pair
         d = _lib.ConvWinDesc()
         d.a, d.a_batch_stride, d.a_row_stride = _p(ah), a_batch_stride, a_row_stride
