@@ -122,6 +122,8 @@ SIGNATURES = {
     "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
     "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_batchnorm_fwd": [_P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _F, _I32, _I32, _P],
+    "ac_batchnorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ac_conv1d_window_x3": [C.POINTER(ConvWinDesc), _P],
     "ac_conv1d_wgrad_bf16": [C.POINTER(WgradDesc), _P],
     "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],

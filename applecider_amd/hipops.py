@@ -880,6 +880,52 @@ def layer_norm(x, gamma, beta, eps=1e-5, act=None):
     return _LayerNorm.apply(x, gamma, beta, float(eps), ACT_CODES[act])
 
 
+class _BatchNormAct(Function):
+    """act(BatchNorm1d(x)) over the columns of x [rows, C] (rows = B*L positions of a channels-last
+    sequence): SpectraNetBlock with use_ln=False (spectranet.py:21,33-37).  running_mean / running_var are
+    updated in place in training mode, as nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, act):
+        x = _chk(x, "x")
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        y = torch.empty_like(x)
+        stats = torch.empty(4 * Cn, device=x.device, dtype=torch.float32)
+        sums = torch.zeros(2 * Cn, device=x.device, dtype=torch.float32) if training else None
+        _lib.check(_lib_().ac_batchnorm_fwd(_p(x), Cn, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                            _p(y), Cn, _p(stats), _p(sums), rows, Cn, eps, momentum,
+                                            int(training), act, _stream()), "ac_batchnorm_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.cfg = (rows, Cn, int(training), act)
+        ctx.gp, ctx.bp = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        rows, Cn, training, act = ctx.cfg
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(x)
+        gs, bs = _sink(ctx.gp), _sink(ctx.bp)
+        both = gs is not None and bs is not None
+        dg = gs if both else torch.zeros_like(gamma)
+        db = bs if both else torch.zeros(Cn, device=x.device, dtype=torch.float32)
+        work = torch.zeros(5 * Cn, device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().ac_batchnorm_bwd(_p(dy), Cn, _p(x), Cn, _p(gamma), _p(stats), _p(dx), Cn, _p(dg), _p(db),
+                                            _p(work), rows, Cn, training, act, _stream()), "ac_batchnorm_bwd")
+        if both:
+            _grad_written(ctx.gp)
+            _grad_written(ctx.bp)
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batchnorm_act(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, bool(training), float(eps),
+                               float(momentum), ACT_CODES[act])
+
+
 # --------------------------------------------------------------------------- elementwise
 class _Dropout(Function):
     @staticmethod

@@ -51,6 +51,26 @@ class LayerNorm(nn.Module):
         return H.layer_norm(x, self.weight, self.bias, self.eps, act=act)
 
 
+class BatchNorm1d(nn.Module):
+    """nn.BatchNorm1d(C) for channels-last sequences [B, L, C] (statistics over B*L per channel), fused
+    with the activation that follows it; same parameters / buffers / state_dict keys as torch's module."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, act=None):
+        if self.training:
+            self.num_batches_tracked += 1
+        return H.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                               self.eps, self.momentum, act)
+
+
 class Dropout(nn.Module):
     def __init__(self, p):
         super().__init__()

@@ -12,7 +12,8 @@ This branch is 92 % of the model's FLOPs.  Sequences are cha
               the 8-phase Toeplitz form (hipops._ConvGroup1d)
   LN + GELU   one row kernel over the 3*Cout channels of each position
   1x1 conv    plain GEMM, then MaxPool1d(4) as a streaming kernel
-BatchNorm stages (use_ln=False) are not on the default path (default_config.toml:105) and raise.
+BatchNorm stages (use_ln=False; off the default path, default_config.toml:105) run `ac_batchnorm_fwd/bwd`
+(column moments + fused GELU); their statistics are per process.
 """
 
 from __future__ import annotations
@@ -22,20 +23,20 @@ import torch.nn as nn
 
 from .. import hipops as H
 from ..hyrax_compat import hyrax_model
-from ._layers import Conv1dTap, Dropout, LayerNorm, Linear, Marker, PointConv1d
+from ._layers import BatchNorm1d, Conv1dTap, Dropout, LayerNorm, Linear, Marker, PointConv1d
 
 
 class SpectraNetBlock(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_sizes, use_ln=True, do_pool=False):
         super().__init__()
-        if not use_ln:
-            raise NotImplementedError("BatchNorm stages are not on the MI355X path (use_ln=True only)")
         self.do_pool, self.use_ln = do_pool, use_ln
         self.k = len(kernel_sizes)
         self.kernel_sizes = tuple(int(k) for k in kernel_sizes)
         norm_channels = out_channels * self.k
         self.convs = nn.ModuleList([Conv1dTap(in_channels, out_channels, k) for k in self.kernel_sizes])
-        self.norm = LayerNorm(norm_channels)
+        # use_ln=False: nn.BatchNorm1d over the channels (spectranet.py:21); statistics are per process
+        # (no cross-rank synchronisation, as in the reference)
+        self.norm = LayerNorm(norm_channels) if use_ln else BatchNorm1d(norm_channels)
         if do_pool:
             self.total_pooled_channels = norm_channels
             self.downsample = PointConv1d(norm_channels, out_channels)
@@ -47,6 +48,10 @@ class SpectraNetBlock(nn.Module):
         return n % 8 == 0 and k % 8 == 0 and H._big(x.shape[0] * x.shape[1], n, k)
 
     def forward(self, x):  # x: [B, L, Cin] channels-last
+        if not self.use_ln:
+            y = H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs], [c.bias for c in self.convs])
+            y = self.norm(y, act="gelu")
+            return H.maxpool4(self.downsample(y)) if self.do_pool else y
         # a pooled block feeds LN+GELU straight into the 1x1 conv: in bf16 mode that hand-over (and
         # the gradient coming back) is bf16 only — the [B, L, 3*Cout] fp32 tensors are never written
         y = H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs],

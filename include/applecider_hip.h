@@ -333,6 +333,19 @@ int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
                const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
                float p_drop, uint64_t seed, ac_stream_t stream);
 
+/* BatchNorm1d over the columns of a [rows, cols] channels-last tensor (rows = B*L positions) fused with
+ * an activation: SpectraNetBlock with use_ln = False (spectranet.py:21,33-37).  training != 0: batch
+ * statistics (biased variance), running statistics updated with `momentum` (unbiased variance) when the
+ * pointers are given; training == 0: running statistics.  stats = 4*cols floats {mean, rstd, scale,
+ * shift} written by the forward and read by the backward; sums (2*cols, training only) and the first
+ * 2*cols floats of work (5*cols) must be zero on entry.  dgamma / dbeta are accumulated into. */
+int ac_batchnorm_fwd(const float *x, int64_t ld, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, float *y, int64_t ldy, float *stats, float *sums, int64_t rows,
+                     int32_t cols, float eps, float momentum, int32_t training, int32_t act, ac_stream_t stream);
+int ac_batchnorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ld, const float *gamma,
+                     const float *stats, float *dx, int64_t lddx, float *dgamma, float *dbeta, float *work,
+                     int64_t rows, int32_t cols, int32_t training, int32_t act, ac_stream_t stream);
+
 /* Weight gradient of a 'same' Conv1d with the input window resident in LDS (ac_wgrad.hip):
  *   dw[co, t*Cin + ci] += sum_{b, l} dy[b, dy_row_base + l, dy_col_off + co] * x[b, x_row_base + l + t, ci]
  * dy and x are bf16 ([B, rows, row_stride] views, strides / offsets in elements, multiples of 8);

@@ -234,11 +234,17 @@ def focal_loss(logits, target, gamma=2.0, alpha=None, eps=0.0):
 
 
 # ----------------------------------------------------------------------------- C1, C2: SpectraNet
-def spectranet_block(sd, p, x, ksizes, do_pool):
-    """SpectraNetBlock.forward with use_ln=True (spectranet.py:28-41); x is [B,C,L]."""
+def spectranet_block(sd, p, x, ksizes, do_pool, use_ln=True, training=False):
+    """SpectraNetBlock.forward (spectranet.py:28-41); x is [B,C,L].  use_ln=False: nn.BatchNorm1d over
+    the channels (spectranet.py:21,33) — batch statistics and in-place running-statistics update when
+    `training`, running statistics otherwise."""
     y = torch.cat([F.conv1d(x, sd[f"{p}.convs.{i}.weight"], sd[f"{p}.convs.{i}.bias"], padding=k // 2)
                    for i, k in enumerate(ksizes)], 1)
-    y = F.gelu(_ln(sd, p + ".norm", y.permute(0, 2, 1)).permute(0, 2, 1))
+    if use_ln:
+        y = F.gelu(_ln(sd, p + ".norm", y.permute(0, 2, 1)).permute(0, 2, 1))
+    else:
+        y = F.gelu(F.batch_norm(y, sd[p + ".norm.running_mean"], sd[p + ".norm.running_var"],
+                                sd[p + ".norm.weight"], sd[p + ".norm.bias"], training, 0.1, 1e-5))
     if do_pool:
         y = F.conv1d(y, sd[p + ".downsample.weight"], sd[p + ".downsample.bias"])
         y = F.max_pool1d(y, 4)
@@ -246,15 +252,17 @@ def spectranet_block(sd, p, x, ksizes, do_pool):
 
 
 def spectranet_forward(sd, x, kernel_sizes_per_stage, depths=None, head="classifier",
-                       return_stages=False):
+                       return_stages=False, use_ln_stages=None, training=False):
     """SpectraNet.forward (spectranet.py:157-170); x is [B,1,L]."""
     n = len(kernel_sizes_per_stage)
     depths = depths or [1] * n
+    use_ln_stages = use_ln_stages or [True] * n
     stages = []
     for i in range(n):
         for j in range(depths[i]):
             x = spectranet_block(sd, f"all_stages.{i}.{j}", x, kernel_sizes_per_stage[i],
-                                 do_pool=(i < n - 1 and j == depths[i] - 1))
+                                 do_pool=(i < n - 1 and j == depths[i] - 1), use_ln=use_ln_stages[i],
+                                 training=training)
         stages.append(x)
     z = F.adaptive_max_pool1d(x, 1).squeeze(-1)
     z = F.gelu(_ln(sd, head + ".1", _lin(sd, head + ".0", z)))

@@ -25,7 +25,9 @@ def fill_value(name: str, shape, salt: int = 0) -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
     u = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
     leaf = name.rsplit(".", 1)[-1]
-    if leaf == "gamma":  # ConvNeXt layer scale: O(1) so that the blocks are exercised
+    if leaf == "running_var":  # BatchNorm running variance: positive
+        v = 1.0 + 0.5 * u
+    elif leaf == "gamma":  # ConvNeXt layer scale: O(1) so that the blocks are exercised
         v = 0.5 + 0.25 * u
     elif leaf == "weight" and len(shape) == 1:  # LayerNorm scale
         v = 1.0 + 0.1 * u

@@ -158,6 +158,40 @@ def test_spectranet_train_step_golden(dev):
         assert_close(m(batch), g["logits_after_step2"], 5e-3, "logits after two SGD steps")
 
 
+def test_spectranet_batchnorm_golden(dev):
+    """BatchNorm stages (use_ln=False, spectranet.py:21,33) on the HIP path against the reference's own
+    train-mode pass (batch statistics, gradients, running statistics) and eval-mode pass (golden g12)."""
+    from applecider_amd import hipops as H
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    g = gold("g12_spectranet_batchnorm.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    cfg["model"]["SpectraNet"]["use_ln_stages"] = [False] * 5
+    m = build(SpectraNet, cfg, dev)
+    m.classifier[3].p = 0.0          # as in the golden: the head's dropout off, BatchNorm in training mode
+    m.train()
+    b = make_batch(4, seed=12, spec_len=256)
+    x = T(b["spectra"]).to(dev)
+    logits = m((x, None, None))
+    assert_close(logits, g["train.logits"], LOGIT_TOL, "train logits")
+    loss = H.cross_entropy_index(logits, T(b["label"]).to(dev))
+    assert_close(loss, g["train.loss"], LOGIT_TOL, "loss")
+    loss.backward()
+    gr = grads_by_ref_name(m)
+    for k in g.files:
+        if k.startswith("train.grad."):
+            assert_close(compact(gr[k[11:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("after.all_stages"):
+            assert_close(sd[k[6:]], g[k], 1e-4, k)
+    assert int(sd["all_stages.2.0.norm.num_batches_tracked"]) == 1
+    m.eval()
+    with torch.no_grad():
+        assert_close(m((x, None, None)), g["eval.logits"], LOGIT_TOL, "eval logits")
+
+
 @pytest.mark.parametrize("L", [128, 257])
 def test_baselinecls_golden(dev, L):
     from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS

@@ -111,6 +111,40 @@ def test_g10_spectranet_train_step_oracle():
         assert_close(O.spectranet_forward(sd2, T(flux), ks), g["logits_after_step2"], 2e-4, "logits after 2 steps")
 
 
+def test_g12_spectranet_batchnorm_oracle():
+    """SpectraNetBlock with use_ln=False (nn.BatchNorm1d, spectranet.py:21,33): train-mode pass, gradients,
+    running statistics and the eval-mode pass of the reference (golden g12)."""
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    from oracle import functional as O
+    g = gold("g12_spectranet_batchnorm.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    cfg["model"]["SpectraNet"]["use_ln_stages"] = [False] * 5
+    ks = cfg["model"]["SpectraNet"]["kernel_sizes_per_stage"]
+    model = SpectraNet(cfg)
+    assert "all_stages.0.0.norm.running_var" in model.state_dict()
+    sd = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in closed_form_sd(model).items()}
+    b = make_batch(4, seed=12, spec_len=256)
+    logits, stages = O.spectranet_forward(sd, T(b["spectra"]), ks, return_stages=True, use_ln_stages=[False] * 5,
+                                          training=True)
+    for i in (0, 2, 4):
+        assert_close(compact(stages[i].detach().numpy()), g[f"train.stage{i}"], TOL, f"stage{i}")
+    assert_close(logits, g["train.logits"], TOL, "train logits")
+    loss = F.cross_entropy(logits, T(b["label"]))
+    assert_close(loss, g["train.loss"], TOL, "loss")
+    loss.backward()
+    for k in g.files:
+        if k.startswith("train.grad."):
+            assert_close(compact(sd[k[11:]].grad.numpy()), g[k], 1e-4, k)
+        if k.startswith("after.all_stages"):
+            assert_close(sd[k[6:]], g[k], TOL, k)
+    with torch.no_grad():
+        ev = O.spectranet_forward(sd, T(b["spectra"]), ks, use_ln_stages=[False] * 5, training=False)
+    assert_close(ev, g["eval.logits"], 5e-5, "eval logits")
+
+
 @pytest.mark.parametrize("L", [128, 257])
 def test_g5_baselinecls_oracle(L):
     from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
