@@ -138,6 +138,9 @@ SIGNATURES = {
     "ac_softmax_fwd": [_P, _P, _I64, _I32, _P],
     "ac_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _P],
     "ac_adam_flat": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _I32, _P, _P],
+    "ac_adam_flat_dev": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _P, _P, _P],
+    "ac_set_step_counter": [_P],
+    "ac_step_advance": [_P, _P],
     "ac_sgd_flat": [_P, _P, _P, _I64, _F, _F, _F, _I32, _P],
     "ac_sumsq": [_P, _I64, _P, _P],
     "ac_clip_coef": [_P, _F, _P, _P],
@@ -186,6 +189,11 @@ def load():
     global _lib
     _lib = lib
     return lib
+
+
+def loaded():
+    """Every library variant loaded so far."""
+    return list(_libs.values())
 
 
 def strerror(code: int) -> str:

@@ -132,8 +132,10 @@ template <bool SPLIT, bool DROP>
 __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *__restrict__ qkv,
                                                            const uint8_t *__restrict__ pad,
                                                            float *__restrict__ out, float *__restrict__ lse,
-                                                           int T, int H, float p_drop, uint64_t seed) {
+                                                           int T, int H, float p_drop, uint64_t seed,
+                                                           const uint64_t *stepp) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
+    if (DROP) seed = ac_step_seed(seed, stepp);
     const int Tp = (T + 31) & ~31, NB = Tp >> 5;
     unsigned short *Kh = smh, *Vh = Kh + Tp * 16;
     unsigned short *Kl = Vh + Tp * 16, *Vl = Kl + (SPLIT ? Tp * 16 : 0);
@@ -277,8 +279,9 @@ template <bool SPLIT, bool DROP>
 __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     const float *__restrict__ dout, const float *__restrict__ qkv, const uint8_t *__restrict__ pad,
     const float *__restrict__ out, const float *__restrict__ lse, float *__restrict__ dqkv, int T, int H,
-    float p_drop, uint64_t seed) {
+    float p_drop, uint64_t seed, const uint64_t *stepp) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
+    if (DROP) seed = ac_step_seed(seed, stepp);
     const int Tp = (T + 31) & ~31, NB = Tp >> 5, IMG = Tp * 16;
     unsigned short *Qh = smh, *Kh = Qh + IMG, *Vh = Kh + IMG, *Gh = Vh + IMG;   // G = dO
     unsigned short *Ql = Gh + IMG, *Kl = Ql + (SPLIT ? IMG : 0), *Vl = Kl + (SPLIT ? IMG : 0),
@@ -469,7 +472,7 @@ int launch_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
     hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_FWD), lds, st, qkv, pad, out, lse, T,
-                       H, p, seed);
+                       H, p, seed, ac_step_ptr());
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -483,7 +486,7 @@ int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
     hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_BWD), lds, st, dout, qkv, pad, out,
-                       lse, dqkv, T, H, p, seed);
+                       lse, dqkv, T, H, p, seed, ac_step_ptr());
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

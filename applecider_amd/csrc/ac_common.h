@@ -133,6 +133,15 @@ __device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
     return (float)(ac_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
 
+// Device-resident step counter (ac_set_step_counter): when one is registered every dropout / mask
+// generator mixes it into the seed its launch was given, so a captured hipGraph of a whole training
+// step draws a new mask at every replay (the host-side seed baked into the graph stays the same;
+// ac_step_advance bumps the counter inside the graph).  Null: seeds are used as given.
+const uint64_t *ac_step_ptr();   // host side, defined in ac_optim.hip
+__device__ __forceinline__ uint64_t ac_step_seed(uint64_t seed, const uint64_t *stepp) {
+    return stepp ? seed + stepp[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
 __device__ __forceinline__ int64_t ac_rowaddr(const ac_rowmap &m, int r) {
     if (m.r1 == 0) return (int64_t)r * m.s3;
     int q1 = r / m.r1;

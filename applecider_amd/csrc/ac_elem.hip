@@ -53,13 +53,16 @@ __global__ void gate_bwd_kernel(const float *dout, const float *a, const float *
     }
 }
 __global__ void dropout_kernel(const float *x, float *y, int64_t n, float p, float inv_keep,
-                               uint64_t seed, uint64_t offset) {
+                               uint64_t seed, uint64_t offset, const uint64_t *stepp) {
+    seed = ac_step_seed(seed, stepp);
     GSTRIDE(i, n) y[i] = ac_rand01(seed, offset + (uint64_t)i) >= p ? x[i] * inv_keep : 0.f;
 }
 // 16-byte form: same keep decision per element index as the scalar kernel
 __global__ void dropout_vec_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n4, float p,
-                                   float inv_keep, uint64_t seed, uint64_t offset) {
+                                   float inv_keep, uint64_t seed, uint64_t offset,
+                                   const uint64_t *stepp) {
     typedef float d32x4 __attribute__((ext_vector_type(4)));
+    seed = ac_step_seed(seed, stepp);
     GSTRIDE(i, n4) {
         d32x4 v = *(const d32x4 *)(x + 4 * i);
 #pragma unroll
@@ -487,8 +490,9 @@ extern "C" int ac_dropout(const float *x, float *y, int64_t n, float p, uint64_t
                           uint64_t offset, ac_stream_t stream) {
     if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return AC_EINVAL;
     if (n % 4 == 0 && ac_aligned16(x) && ac_aligned16(y))
-        EW_LAUNCH(dropout_vec_kernel, n / 4, x, y, n / 4, p, 1.0f / (1.0f - p), seed, offset);
-    EW_LAUNCH(dropout_kernel, n, x, y, n, p, 1.0f / (1.0f - p), seed, offset);
+        EW_LAUNCH(dropout_vec_kernel, n / 4, x, y, n / 4, p, 1.0f / (1.0f - p), seed, offset,
+                  ac_step_ptr());
+    EW_LAUNCH(dropout_kernel, n, x, y, n, p, 1.0f / (1.0f - p), seed, offset, ac_step_ptr());
 }
 extern "C" int ac_add(const float *a, const float *b, float *y, int64_t n, float alpha,
                       ac_stream_t stream) {

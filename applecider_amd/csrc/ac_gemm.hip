@@ -34,6 +34,7 @@ struct GemmParams {
     int tiles_m, tiles_n, nkt, kt_per_split;
     int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
     int epi_var;  // compile-time epilogue variant (AC_EPI_VARIANTS index) or EPI_GENERIC
+    const uint64_t *stepp;  // ac_set_step_counter()'s device counter (or null): mixed into drop_seed
 };
 
 // round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
@@ -48,7 +49,7 @@ __device__ __forceinline__ int64_t inner_off(const int32_t *goff, int i) {
     return goff ? (int64_t)goff[i >> 5] + (i & 31) : (int64_t)i;
 }
 
-__device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int n, float acc,
+__device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, uint64_t dseed, int m, int n, float acc,
                                                int64_t caddr) {
     float v = acc * d.alpha;
     if (d.bias) v += d.bias[n];
@@ -58,7 +59,7 @@ __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, int m, int
     if (d.mask16) v = epi_bf16_to_f32(((const unsigned short *)d.mask16)[(int64_t)m * d.ld_mask16 + n]) > 0.f ? v : 0.f;
     if (d.colscale) v *= d.colscale[n];
     if (d.drop_p > 0.f)
-        v = ac_rand01(d.drop_seed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n) >= d.drop_p
+        v = ac_rand01(dseed, (uint64_t)m * (uint64_t)d.N + (uint64_t)n) >= d.drop_p
                 ? v * (1.0f / (1.0f - d.drop_p)) : 0.f;
     if (d.residual) v += d.residual[(int64_t)m * d.ld_res + n];
     if (d.c16) ((unsigned short *)d.c16)[(int64_t)m * d.ld_c16 + inner_off(d.c.goff, n)] = epi_bf16(v);
@@ -82,7 +83,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // epilogue: reg e of a 32x32 tile holds row (e&3)+8*(e>>2)+4*lh, col li.
 // Compile-time register indices keep the accumulators out of scratch.
-__device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+__device__ __forceinline__ void store_tile(const ac_gemm_desc &d, uint64_t dseed, const f32x16 (&acc)[2][2],
                                            int row_base, int col_base, int li, int lh) {
     const int n0 = col_base + li, n1 = n0 + 32;
     const int64_t c0 = inner_off(d.c.goff, n0 < d.N ? n0 : 0);
@@ -92,8 +93,8 @@ __device__ __forceinline__ void store_tile(const ac_gemm_desc &d, const f32x16 (
         const int m = row_base + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m < d.M) {
             const int64_t crow = ac_rowaddr(d.c.rows, m);
-            if (n0 < d.N) epilogue_store(d, m, n0, acc[sa][0][e], crow + c0);
-            if (n1 < d.N) epilogue_store(d, m, n1, acc[sa][1][e], crow + c1);
+            if (n0 < d.N) epilogue_store(d, dseed, m, n0, acc[sa][0][e], crow + c0);
+            if (n1 < d.N) epilogue_store(d, dseed, m, n1, acc[sa][1][e], crow + c1);
         }
     });
 }
@@ -124,7 +125,7 @@ __device__ __forceinline__ void store_tile_atomic(const ac_gemm_desc &d, const f
 // LDS and re-reads it row-major, so every lane handles 4 consecutive columns of one row: bias /
 // aux / residual come in as float4 and C goes out as float4 — 4x fewer memory instructions than the
 // one-float-per-lane accumulator layout (the memory-bound small-K products were store-issue bound).
-__device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n, f32x4 v,
+__device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
                                              int64_t caddr) {
     v *= d.alpha;
     if (d.bias) v += *(const f32x4 *)(d.bias + n);
@@ -150,7 +151,7 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, int m, int n
         const float inv_keep = 1.0f / (1.0f - d.drop_p);
         const uint64_t i0 = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(d.drop_seed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(dseed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
     }
     if (d.residual) v += *(const f32x4 *)(d.residual + (int64_t)m * d.ld_res + n);
     if (d.c16) {
@@ -191,7 +192,7 @@ enum : unsigned {
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
-__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int n, f32x4 v,
+__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
                                                const f32x4 &bias4, const f32x4 &cs4, int64_t ccol) {
     v *= d.alpha;
     if constexpr (F & E_BIAS) v += bias4;  // per-column vectors are loaded once per tile
@@ -221,7 +222,7 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int
         const float inv_keep = 1.0f / (1.0f - d.drop_p);
         const uint64_t i0 = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(d.drop_seed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = ac_rand01(dseed, i0 + j) >= d.drop_p ? v[j] * inv_keep : 0.f;
     }
     if constexpr (F & E_RES) v += *(const f32x4 *)(d.residual + (int64_t)m * d.ld_res + n);
     if constexpr (F & E_C16) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, int m, int
 }
 
 template <int VAR>
-__device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f32x16 (&acc)[2][2],
+__device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, uint64_t dseed, const f32x16 (&acc)[2][2],
                                                  float *wbuf, int row_base, int col_base, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
@@ -264,9 +265,9 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
             const int m = row_base + sa * 32 + r;
             if (m < d.M && n < d.N) {
                 if constexpr (VAR == EPI_GENERIC) {
-                    epilogue_vec(d, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
+                    epilogue_vec(d, dseed, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
                 } else {
-#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, m, n, v, bias4, cs4, coff);
+#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, dseed, m, n, v, bias4, cs4, coff);
                     AC_EPI_VARIANTS(AC_EPI_CALL)
 #undef AC_EPI_CALL
                 }
@@ -275,14 +276,14 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, const f3
     });
 }
 
-__device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, int variant,
+__device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, uint64_t dseed, int variant,
                                                const f32x16 (&acc)[2][2], float *wbuf, int row_base,
                                                int col_base, int lane) {
     switch (variant) {
-#define AC_EPI_CASE(I, F) case I: store_tile_vec_t<I>(d, acc, wbuf, row_base, col_base, lane); break;
+#define AC_EPI_CASE(I, F) case I: store_tile_vec_t<I>(d, dseed, acc, wbuf, row_base, col_base, lane); break;
         AC_EPI_VARIANTS(AC_EPI_CASE)
 #undef AC_EPI_CASE
-        default: store_tile_vec_t<EPI_GENERIC>(d, acc, wbuf, row_base, col_base, lane); break;
+        default: store_tile_vec_t<EPI_GENERIC>(d, dseed, acc, wbuf, row_base, col_base, lane); break;
     }
 }
 
@@ -419,6 +420,7 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -497,9 +499,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+        store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
-        store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile(d, dseed, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm16 = reinterpret_cast<unsigned short *>(smem);
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -632,9 +635,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+        store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
-        store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile(d, dseed, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 // ---------------------------------------------------------------------------
@@ -874,6 +877,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     constexpr int B_IMG = B_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -971,9 +975,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
+        store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
     else
-        store_tile(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile(d, dseed, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
 template <bool A_KC, bool B_KC>
@@ -1007,6 +1011,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm = reinterpret_cast<unsigned short *>(smem);
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -1132,9 +1137,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
     else if (p.vec_epi)
-        store_tile_vec(d, p.epi_var, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
+        store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, lane);
     else
-        store_tile(d, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
+        store_tile(d, dseed, acc, tm * Cfg::TM + wm * 64, tn * Cfg::TNn + wn * 64, li, lh);
 }
 
 template <bool TN, int WM, int WN>
@@ -1241,6 +1246,7 @@ __global__ __launch_bounds__(256) void transpose_cast_segments_kernel(
 // ---------------------------------------------------------------------------
 __global__ void gemm_simple_kernel(GemmParams p) {
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)d.M * d.N) return;
     int m = (int)(idx / d.N), n = (int)(idx % d.N);
@@ -1259,13 +1265,14 @@ __global__ void gemm_simple_kernel(GemmParams p) {
         for (int k = 0; k < d.K; ++k)
             acc = fmaf(A[ac_rowaddr(d.a.rows, k) + ai], B[ac_rowaddr(d.b.rows, k) + bi], acc);
     }
-    epilogue_store(d, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
+    epilogue_store(d, dseed, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
 }
 
 // TN with tiny M x N and a long reduction (tower / router weight gradients: K = batch rows):
 // one wave per output element, lanes stride the reduction, shuffle-reduce.
 __global__ __launch_bounds__(256) void gemm_simple_tn_wave_kernel(GemmParams p) {
     const ac_gemm_desc &d = p.d;
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
     const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (widx >= (int64_t)d.M * d.N) return;
     const int lane = threadIdx.x & 63;
@@ -1276,7 +1283,7 @@ __global__ __launch_bounds__(256) void gemm_simple_tn_wave_kernel(GemmParams p) 
     for (int k = lane; k < d.K; k += 64)
         acc = fmaf(A[ac_rowaddr(d.a.rows, k) + ai], B[ac_rowaddr(d.b.rows, k) + bi], acc);
     acc = ac_wave_sum(acc);
-    if (lane == 0) epilogue_store(d, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
+    if (lane == 0) epilogue_store(d, dseed, m, n, acc, ac_rowaddr(d.c.rows, m) + inner_off(d.c.goff, n));
 }
 
 bool rowmap_aligned(const ac_rowmap &r) {
@@ -1354,6 +1361,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
             return AC_EALIGN;
         GemmParams p;
         p.d = d;
+        p.stepp = ac_step_ptr();
         if (d.split_k > 1) p.d.accumulate = 2;
         if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
@@ -1387,6 +1395,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
 
     GemmParams p;
     p.d = d;
+    p.stepp = ac_step_ptr();
     if (!use_mfma) {
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.

@@ -16,8 +16,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p,
                                                    int64_t begin, int64_t end, float lr,
                                                    float beta1, float beta2, float eps, float wd,
                                                    int decoupled, float bc1, float bc2_sqrt,
-                                                   const float *__restrict__ gscale) {
+                                                   const float *__restrict__ gscale,
+                                                   const int64_t *__restrict__ step_dev) {
     const float gs = gscale ? gscale[0] : 1.0f;
+    if (step_dev) {  // step count lives in HBM (captured hipGraph): bias corrections computed here
+        const float st = (float)step_dev[0];
+        bc1 = 1.0f - powf(beta1, st);
+        bc2_sqrt = sqrtf(1.0f - powf(beta2, st));
+    }
     const float step_size = lr / bc1;
     for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -66,6 +72,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+__global__ void step_advance_kernel(uint64_t *c) { c[0] += 1; }
+
 __global__ void clip_coef_kernel(const float *sumsq, float max_norm, float *coef) {
     const float total = sqrtf(sumsq[0]);
     const float c = max_norm / (total + 1e-6f);
@@ -79,12 +87,49 @@ inline int stream_grid(int64_t n) {
     return (int)g;
 }
 
+const uint64_t *g_step_counter = nullptr;
+
+int adam_launch(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                const ac_adam_seg *segs, int32_t nseg, int32_t step, const int64_t *step_dev,
+                const float *grad_scale_dev, ac_stream_t stream);
+
 }  // namespace
+
+const uint64_t *ac_step_ptr() { return g_step_counter; }
+
+extern "C" int ac_set_step_counter(const uint64_t *counter_dev) {
+    g_step_counter = counter_dev;
+    return AC_OK;
+}
+
+extern "C" int ac_step_advance(uint64_t *counter_dev, ac_stream_t stream) {
+    if (!counter_dev) return AC_EINVAL;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
 
 extern "C" int ac_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                             const ac_adam_seg *segs, int32_t nseg, int32_t step,
                             const float *grad_scale_dev, ac_stream_t stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || step < 1)
+    if (step < 1) return AC_EINVAL;
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, segs, nseg, step, nullptr, grad_scale_dev,
+                       stream);
+}
+
+extern "C" int ac_adam_flat_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                const ac_adam_seg *segs, int32_t nseg, const int64_t *step_dev,
+                                const float *grad_scale_dev, ac_stream_t stream) {
+    if (!step_dev) return AC_EINVAL;
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, segs, nseg, 1, step_dev, grad_scale_dev,
+                       stream);
+}
+
+namespace {
+int adam_launch(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                const ac_adam_seg *segs, int32_t nseg, int32_t step, const int64_t *step_dev,
+                const float *grad_scale_dev, ac_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0)
         return AC_EINVAL;
     for (int s = 0; s < nseg; ++s) {
         const ac_adam_seg &g = segs[s];
@@ -95,11 +140,12 @@ extern "C" int ac_adam_flat(float *param, const float *grad, float *exp_avg, flo
         hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(g.end - g.begin)), dim3(256), 0,
                            (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, g.begin, g.end,
                            g.lr, g.beta1, g.beta2, g.eps, g.weight_decay, g.decoupled, bc1,
-                           sqrtf(bc2), grad_scale_dev);
+                           sqrtf(bc2), grad_scale_dev, step_dev);
         AC_CHECK_LAUNCH();
     }
     return AC_OK;
 }
+}  // namespace
 
 extern "C" int ac_sgd_flat(float *param, const float *grad, float *momentum_buf, int64_t n,
                            float lr, float momentum, float weight_decay, int32_t first_step,

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
                                                       const uint8_t *__restrict__ pad,
                                                       float *__restrict__ out,
                                                       float *__restrict__ lse, int T, int H,
-                                                      float p_drop, uint64_t seed) {
+                                                      float p_drop, uint64_t seed,
+                                                      const uint64_t *stepp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    seed = ac_step_seed(seed, stepp);
     float *Ks = sm, *Vs = sm + T * DH;
     float *msk = sm + 2 * T * DH;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -143,8 +145,9 @@ template <int DH>
 __global__ __launch_bounds__(256) void mha_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ qkv, const uint8_t *__restrict__ pad,
     const float *__restrict__ out, const float *__restrict__ lse, float *__restrict__ dqkv, int T,
-    int H, float p_drop, uint64_t seed) {
+    int H, float p_drop, uint64_t seed, const uint64_t *stepp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    seed = ac_step_seed(seed, stepp);
     float *T0 = sm, *T1 = sm + T * DH;  // phase A: K, V ; phase B: Q*scale, dO
     float *msk = sm + 2 * T * DH, *lses = msk + T, *Dv = lses + T;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -254,7 +257,9 @@ constexpr int MPT_MAXL = 2048;
 __global__ __launch_bounds__(64) void mpt_mask_kernel(float *__restrict__ x,
                                                       const uint8_t *__restrict__ pad,
                                                       uint8_t *__restrict__ masked, int L,
-                                                      double mask_p, uint64_t seed) {
+                                                      double mask_p, uint64_t seed,
+                                                      const uint64_t *stepp) {
+    seed = ac_step_seed(seed, stepp);
     __shared__ unsigned short lst[MPT_MAXL];
     __shared__ unsigned char sel[MPT_MAXL], band[MPT_MAXL];
     const int b = blockIdx.x;
@@ -428,10 +433,10 @@ extern "C" int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, floa
     dim3 grid(B * H);
     if (Dh == 16)
         hipLaunchKernelGGL(mha_fwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, pad,
-                           out, lse, T, H, p_drop, seed);
+                           out, lse, T, H, p_drop, seed, ac_step_ptr());
     else if (Dh == 32)
         hipLaunchKernelGGL(mha_fwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, qkv, pad,
-                           out, lse, T, H, p_drop, seed);
+                           out, lse, T, H, p_drop, seed, ac_step_ptr());
     else
         return AC_EINVAL;
     AC_CHECK_LAUNCH();
@@ -448,10 +453,10 @@ extern "C" int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pa
     dim3 grid(B * H);
     if (Dh == 16)
         hipLaunchKernelGGL(mha_bwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, dout, qkv,
-                           pad, out, lse, dqkv, T, H, p_drop, seed);
+                           pad, out, lse, dqkv, T, H, p_drop, seed, ac_step_ptr());
     else if (Dh == 32)
         hipLaunchKernelGGL(mha_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, dout, qkv,
-                           pad, out, lse, dqkv, T, H, p_drop, seed);
+                           pad, out, lse, dqkv, T, H, p_drop, seed, ac_step_ptr());
     else
         return AC_EINVAL;
     AC_CHECK_LAUNCH();
@@ -463,7 +468,7 @@ extern "C" int ac_mpt_mask(float *x, const uint8_t *pad, uint8_t *masked, int32_
     if (!x || !pad || !masked || B <= 0 || L <= 0 || L > MPT_MAXL || mask_p < 0.0 || mask_p > 1.0)
         return AC_EINVAL;
     hipLaunchKernelGGL(mpt_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, pad, masked, L,
-                       mask_p, seed);
+                       mask_p, seed, ac_step_ptr());
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

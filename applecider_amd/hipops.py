@@ -50,6 +50,8 @@ def set_math(mode: str):
         _MATH_EPOCH += 1
         _step_cache.clear()
     _MODE = mode
+    if _STEP_DEV is not None:   # the library variant selected now must know the step counter too
+        _lib.check(_lib_().ac_set_step_counter(_p(_STEP_DEV)), "ac_set_step_counter")
 
 
 def get_math() -> str:
@@ -526,6 +528,38 @@ def set_seed_offset(rank: int):
     (ddp.init_from_env calls this with the rank)."""
     global _seed_offset
     _seed_offset = int(rank)
+
+
+_STEP_DEV = None
+
+
+def enable_device_step(device=None) -> torch.Tensor:
+    """Registers a device-resident step counter with the library (ac_set_step_counter): from now on every
+    dropout / mask generator mixes counter[0] into the seed its launch carries, so a captured hipGraph
+    of a training step draws new masks at every replay.  Advance it once per step with step_advance()
+    (GraphedTrainStep does).  Returns the counter (int64[1]; the kernels read it as uint64)."""
+    global _STEP_DEV
+    if _STEP_DEV is None:
+        _STEP_DEV = torch.zeros(1, dtype=torch.int64, device=device or torch.device("cuda", torch.cuda.current_device()))
+    _lib.check(_lib_().ac_set_step_counter(_p(_STEP_DEV)), "ac_set_step_counter")
+    return _STEP_DEV
+
+
+def disable_device_step():
+    """Back to plain host seeds (every loaded library variant)."""
+    global _STEP_DEV
+    if _STEP_DEV is not None:
+        for lib in _lib.loaded():
+            _lib.check(lib.ac_set_step_counter(None), "ac_set_step_counter")
+    _STEP_DEV = None
+
+
+def step_advance(counter: Optional[torch.Tensor] = None):
+    """counter[0] += 1 on the current stream (default: the registered dropout step counter)."""
+    c = _STEP_DEV if counter is None else counter
+    if c is None:
+        raise RuntimeError("no device step counter: call hipops.enable_device_step() first")
+    _lib.check(_lib_().ac_step_advance(_p(c), _stream()), "ac_step_advance")
 
 
 def next_seed() -> int:
@@ -1806,6 +1840,14 @@ def adam_flat(param, grad, exp_avg, exp_avg_sq, segs, step, grad_scale_dev=None)
     _lib.check(_lib_().ac_adam_flat(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), arr,
                                     len(segs), step, _p(grad_scale_dev), _stream()),
                "ac_adam_flat")
+
+
+def adam_flat_dev(param, grad, exp_avg, exp_avg_sq, segs, step_dev, grad_scale_dev=None):
+    """adam_flat with the step count read from device memory (int64[1]): graph-capturable."""
+    arr = (AdamSeg * len(segs))(*segs)
+    _lib.check(_lib_().ac_adam_flat_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), arr,
+                                        len(segs), _p(step_dev), _p(grad_scale_dev), _stream()),
+               "ac_adam_flat_dev")
 
 
 def sgd_flat(param, grad, buf, lr, momentum, weight_decay, first_step):

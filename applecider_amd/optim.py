@@ -130,6 +130,19 @@ class FlatAdam:
         self.decoupled = decoupled
         self.step_count = 0
         self.exp_avg = self.exp_avg_sq = None
+        # capturable=True (torch.optim's name for it): the step count also lives in HBM and the kernel
+        # computes the bias corrections from it, so step() can sit inside a captured hipGraph
+        self.capturable = False
+        self.step_dev = None
+
+    def set_capturable(self, on: bool = True):
+        self._ensure()
+        self.capturable = bool(on)
+        if on:
+            if self.step_dev is None:
+                self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.fp.flat.device)
+            self.step_dev.fill_(self.step_count)
+        return self
 
     def _ensure(self):
         old = None
@@ -187,6 +200,8 @@ class FlatAdam:
         if st:
             self._load_moments([(st[i]["exp_avg"], st[i]["exp_avg_sq"]) for i in range(len(self.fp.params))])
             self.step_count = int(float(st[0]["step"]))
+            if self.step_dev is not None:
+                self.step_dev.fill_(self.step_count)
 
     def prepare(self):
         """Flatten now (call after the model sits on its GPU; train_step does it lazily)."""
@@ -210,8 +225,13 @@ class FlatAdam:
         for g, (b, e) in zip(self.param_groups, self.fp.group_ranges):
             segs.append(AdamSeg(b, e, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                 float(g["eps"]), float(g["weight_decay"]), int(self.decoupled)))
-        H.adam_flat(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_count,
-                    getattr(self, "_clip", None))
+        if self.capturable:
+            H.step_advance(self.step_dev)
+            H.adam_flat_dev(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_dev,
+                            getattr(self, "_clip", None))
+        else:
+            H.adam_flat(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, segs, self.step_count,
+                        getattr(self, "_clip", None))
         self._clip = None
         self.fp.mirror_dirty = True
         H.clear_step_cache()  # cached bf16 weight copies are stale now

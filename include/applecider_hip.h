@@ -443,8 +443,27 @@ typedef struct ac_adam_seg {
 int ac_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                  const ac_adam_seg *segs_host, int32_t nseg, int32_t step,
                  const float *grad_scale_dev, ac_stream_t stream);
+/* Same step with the 1-based step count read from DEVICE memory (bias corrections computed in the
+ * kernel): nothing about the step number is baked into the launch, so a captured hipGraph of a
+ * whole training step (zero_grad .. optimizer) replays correctly.  torch keeps `state["step"]` as
+ * a tensor for the same reason (capturable=True). */
+int ac_adam_flat_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                     const ac_adam_seg *segs_host, int32_t nseg, const int64_t *step_dev,
+                     const float *grad_scale_dev, ac_stream_t stream);
 int ac_sgd_flat(float *param, const float *grad, float *momentum_buf, int64_t n, float lr,
                 float momentum, float weight_decay, int32_t first_step, ac_stream_t stream);
+/* Device-resident step counter for graph capture.
+ *   ac_step_advance(counter, stream): counter[0] += 1 on the stream (one tiny kernel).
+ *   ac_set_step_counter(counter | NULL): registers a counter with the library; from then on every
+ *   random generator on the path (ac_dropout, the GEMM epilogue's dropout, ac_mha_* attention
+ *   dropout, ac_mpt_mask) uses seed' = seed + counter[0] * 0x9E3779B97F4A7C15 instead of the seed
+ *   its launch was given.  Forward and backward of one step read the same counter value, so their
+ *   masks agree; a replayed graph (same host seeds) draws new masks once the counter advanced.
+ *   The replacement for torch's philox (seed, offset) pair kept on the device by CUDA graphs
+ *   (nn.Dropout / MultiheadAttention dropout: photo_events.py:55-64, HyraxBaselineCLS.py:31).
+ *   NULL (default) restores plain host seeds.  Process-wide, not thread-safe. */
+int ac_set_step_counter(const uint64_t *counter_dev);
+int ac_step_advance(uint64_t *counter_dev, ac_stream_t stream);
 /* out[0] = sum x^2 (zeroed by the call); clip coefficient computed on device:
  * coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)). */
 int ac_sumsq(const float *x, int64_t n, float *out, ac_stream_t stream);

@@ -1,0 +1,219 @@
+"""Whole-step hipGraph (applecider_amd/graphstep.py) and the device-resident step counter behind it.
+
+Properties checked, all through the C ABI on the GPU:
+  * a registered counter at 0 changes nothing; another value changes every generator's mask, forward and
+    backward consistently (standalone dropout, the GEMM epilogue's dropout, attention dropout on both
+    kernel families);
+  * Adam with the step count in HBM == Adam with the host step count;
+  * N replays of the captured step == N eager steps of the fused 4-modality model, dropout ON (the eager
+    run uses the same counter and the same host seeds), parameters and losses compared;
+  * constructing the graph does not train (state restored), replays draw different masks, a changed
+    learning rate re-captures.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.4,
+       "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3,
+       "beta1": 0.9, "beta2": 0.999, "weight_decay": 0.01}
+
+
+@pytest.fixture()
+def dev():
+    from applecider_amd import hipops as H
+    H.set_math("f32")
+    yield torch.device("cuda:0")
+    H.disable_device_step()
+    H.set_math("f32")
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_counter_zero_is_identity_and_nonzero_changes_masks(dev):
+    from applecider_amd import hipops as H
+    x = torch.randn(4096, 64, device=dev)
+    seed = 1234567
+    y_plain = H._Dropout.apply(x, 0.3, seed) if hasattr(H, "_Dropout") else None
+    if y_plain is None:
+        pytest.skip("no seeded dropout entry")
+    c = H.enable_device_step(dev)
+    c.zero_()
+    assert torch.equal(H._Dropout.apply(x, 0.3, seed), y_plain)
+    c.fill_(3)
+    y3 = H._Dropout.apply(x, 0.3, seed)
+    assert not torch.equal(y3, y_plain)
+    assert abs((y3 == 0).float().mean().item() - 0.3) < 0.01
+    H.step_advance()
+    torch.cuda.synchronize()
+    assert int(c.item()) == 4
+    y4 = H._Dropout.apply(x, 0.3, seed)
+    assert not torch.equal(y4, y3)
+    H.disable_device_step()
+    assert torch.equal(H._Dropout.apply(x, 0.3, seed), y_plain)
+
+
+def test_dropout_backward_uses_the_same_counter(dev):
+    """Forward and backward of one step read the same counter value: d/dx of dropout is the mask."""
+    from applecider_amd import hipops as H
+    c = H.enable_device_step(dev)
+    c.fill_(11)
+    x = torch.randn(512, 96, device=dev, requires_grad=True)
+    y = H.dropout(x, 0.5, True)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, y.detach() != 0) or (x.detach() == 0).any()
+    assert torch.allclose(x.grad[y.detach() != 0], torch.full((1,), 2.0, device=dev))
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_attention_dropout_with_counter_matches_scalar_kernels(dev, mode):
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    c = H.enable_device_step(dev)
+    B, T, NH, D = 2, 129, 8, 128
+    gen = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, T, 3 * D, generator=gen).to(dev)
+    go = torch.randn(B, T, D, generator=gen).to(dev)
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    pad[1, 40:] = 1
+    pad = pad.to(dev)
+    out = {}
+    for cnt in (0, 9):
+        c.fill_(cnt)
+        for name, flag in (("mfma", True), ("scalar", False)):
+            H._MHA_MFMA = flag
+            try:
+                q = qkv.clone().requires_grad_()
+                o = H._MHA.apply(q, pad, NH, 0.4, 4242)
+                o.backward(go)
+                out[(cnt, name)] = (o.detach(), q.grad)
+            finally:
+                H._MHA_MFMA = True
+        assert _rel(out[(cnt, "mfma")][0], out[(cnt, "scalar")][0]) <= 1e-4
+        assert _rel(out[(cnt, "mfma")][1], out[(cnt, "scalar")][1]) <= 2e-4
+    assert _rel(out[(9, "scalar")][0], out[(0, "scalar")][0]) > 0.05   # another step, another mask
+
+
+def test_gemm_epilogue_dropout_with_counter_matches_standalone(dev):
+    """Linear + fused dropout (GEMM epilogue generator) == linear then ac_dropout under the same seed and
+    the same counter: both mix the counter the same way."""
+    from applecider_amd import hipops as H
+    c = H.enable_device_step(dev)
+    x = torch.randn(256, 128, device=dev)
+    w = torch.randn(64, 128, device=dev) * 0.1
+    b = torch.randn(64, device=dev)
+    M, N, K = x.shape[0], w.shape[0], x.shape[1]
+    seed = 777
+    for force_simple in (0, 1):          # matrix-core kernel (16-byte epilogue) and the scalar kernel
+        for cnt in (0, 5):
+            c.fill_(cnt)
+            y_fused = torch.empty(M, N, device=dev)
+            H.gemm(0, M, N, K, H.mat(x.data_ptr(), K), H.mat(w.data_ptr(), K), H.mat(y_fused.data_ptr(), N),
+                   bias=b, drop_p=0.4, drop_seed=seed, force_simple=force_simple)
+            y_ref = H._Dropout.apply(H.linear(x, w, b), 0.4, seed)
+            assert torch.equal(y_fused == 0, y_ref == 0)
+            assert _rel(y_fused, y_ref) <= 1e-5
+
+
+def test_adam_device_step_equals_host_step(dev):
+    from applecider_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(1000, device=dev)), torch.nn.Parameter(torch.randn(37, 5, device=dev))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a = FlatAdam([{"params": ps}], lr=1e-2, weight_decay=0.01, decoupled=True).prepare()
+    b = FlatAdam([{"params": qs}], lr=1e-2, weight_decay=0.01, decoupled=True).prepare()
+    b.set_capturable(True)
+    for it in range(4):
+        g = [torch.randn_like(p) for p in ps]
+        a.zero_grad(); b.zero_grad()
+        for p, q, gi in zip(ps, qs, g):
+            p.grad.add_(gi); q.grad.add_(gi)
+        a.step(); b.step()
+    assert int(b.step_dev.item()) == 4 == b.step_count
+    for p, q in zip(ps, qs):
+        assert _rel(q, p) <= 2e-6
+
+
+def _fused(dev, B=8):
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    m = AppleCider(dict(CFG)).to(dev).train()
+    bs = []
+    for s in (2, 3, 4):
+        b = make_batch(B, seed=s)
+        bs.append(tuple(torch.from_numpy(b[k]).to(dev) for k in
+                        ("photometry", "pad_mask", "metadata", "image", "spectra", "label")))
+    return m, bs
+
+
+def _step_fn(model, batch):
+    from applecider_amd import hipops as H
+    H._seed_counter = itertools.count(5000)     # the same host seeds every step: only the device counter varies
+    return model.train_step(batch)["loss"]
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_graph_replays_equal_eager_steps_with_dropout_on(dev, mode):
+    from applecider_amd import hipops as H
+    from applecider_amd.graphstep import GraphedTrainStep
+    H.set_math(mode)
+    # eager run: device counter registered, advanced by hand
+    m1, batches = _fused(dev)
+    m1.optimizer.prepare().set_capturable(True)
+    c = H.enable_device_step(dev)
+    c.zero_()
+    eager_losses = []
+    for bt in batches:
+        H.step_advance()
+        eager_losses.append(float(_step_fn(m1, bt)))
+    p_eager = m1.optimizer.fp.flat.clone()
+    # graphed run from the same initial state
+    m2, _ = _fused(dev)
+    c.zero_()
+    p0 = m2.optimizer.prepare().fp.flat.clone()
+    step = GraphedTrainStep(m2, batches[0], step_fn=_step_fn)
+    torch.cuda.synchronize()
+    assert torch.equal(m2.optimizer.fp.flat, p0), "constructing the graph must not train"
+    assert int(c.item()) == 0 and m2.optimizer.step_count == 0
+    graph_losses = [float(step(bt)) for bt in batches]
+    assert m2.optimizer.step_count == 3 and int(m2.optimizer.step_dev.item()) == 3 and int(c.item()) == 3
+    # atomics in the weight-gradient kernels make two runs differ in the last bits
+    np.testing.assert_allclose(graph_losses, eager_losses, rtol=2e-5)
+    # Adam divides by sqrt(v): where a gradient is ~0 the last-bit noise of the atomics moves the update by a
+    # visible fraction of lr, so the parameter bound is looser than the loss bound; the bulk agrees tightly
+    d = (m2.optimizer.fp.flat - p_eager).abs()
+    assert _rel(m2.optimizer.fp.flat, p_eager) <= 1e-3
+    assert (d > 1e-5).float().mean().item() < 1e-3
+    assert len(set(round(l, 6) for l in graph_losses)) == 3
+
+
+def test_graph_replays_draw_new_masks_and_recapture_on_lr_change(dev):
+    from applecider_amd import hipops as H
+    from applecider_amd.graphstep import GraphedTrainStep
+    m, batches = _fused(dev)
+    for g in m.optimizer.param_groups:
+        g["lr"] = 0.0
+        g["weight_decay"] = 0.0
+    step = GraphedTrainStep(m, batches[0], step_fn=_step_fn)
+    # lr = 0: parameters stand still, so a loss that changes between replays of the SAME batch is the mask
+    l1 = float(step(batches[0]))
+    l2 = float(step(batches[0]))
+    assert l1 != l2
+    step.counter.fill_(0)            # rewind the counter: the first replay again
+    assert float(step(batches[0])) == pytest.approx(l1, rel=2e-5)
+    assert step.captures == 1
+    for g in m.optimizer.param_groups:
+        g["lr"] = 1e-3
+    p0 = m.optimizer.fp.flat.clone()
+    step(batches[1])
+    assert step.captures == 2
+    assert not torch.equal(m.optimizer.fp.flat, p0)
+    with pytest.raises(ValueError):
+        step(tuple(t[:4] for t in batches[0]))

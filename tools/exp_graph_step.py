@@ -1,26 +1,27 @@
-"""Experiment: upper bound of capturing the whole training step in a HIP graph (seeds and the Adam step
-count are baked in, so this is a timing probe only, not a training mode)."""
+"""Probe: whole training step through applecider_amd.graphstep.GraphedTrainStep at a given (mode, batch,
+encoder streams) — eager vs replay time.  usage: exp_graph_step.py [mode] [B] [streams 0|1]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 from applecider_amd import hipops as H
+from applecider_amd.graphstep import GraphedTrainStep
 from applecider_amd.models.applecider import AppleCider
 from applecider_amd.synthetic import make_batch
 import bench
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+streams = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 dev = torch.device("cuda:0")
-H.set_math("bf16")
+H.set_math(mode)
 torch.manual_seed(0)
 model = AppleCider(dict(bench.FUSION_CFG)).to(dev).train()
+model.branch_streams = streams
 opt = model.optimizer.prepare()
-b = make_batch(512, seed=2)
+b = make_batch(B, seed=2)
 batch = tuple(torch.from_numpy(b[k]).to(dev) for k in ("photometry", "pad_mask", "metadata", "image", "spectra", "label"))
 
 def step():
-    opt.zero_grad()
-    loss = H.cross_entropy_index(model(*batch[:5]), batch[5])
-    loss.backward()
-    opt.step()
-    return loss
+    return model.train_step(batch)["loss"]
 
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
@@ -30,15 +31,7 @@ def timeit(fn, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 for _ in range(3): step()
-print("eager ms/step", round(timeit(step), 3), flush=True)
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(2): step()
-torch.cuda.current_stream().wait_stream(side)
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    static_loss = step()
-torch.cuda.synchronize()
-print("graph ms/step", round(timeit(g.replay), 3), "loss", float(static_loss), flush=True)
+print(mode, B, streams, "eager ms/step", round(timeit(step), 3), flush=True)
+gs = GraphedTrainStep(model, batch, restore_state=False)
+print("captured", flush=True)
+print(mode, B, streams, "graph ms/step", round(timeit(gs), 3), "loss", float(gs.loss), flush=True)
