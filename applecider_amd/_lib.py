@@ -46,7 +46,7 @@ class GemmDesc(C.Structure):
         ("colscale", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),
         ("c16", C.c_void_p), ("ld_c16", C.c_int64),
         ("mask16", C.c_void_p), ("ld_mask16", C.c_int64),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_step", C.c_void_p),
     ]
 
 
@@ -90,7 +90,7 @@ SIGNATURES = {
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _I32, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
                          _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
-    "ac_mpt_mask": [_P, _P, _P, _I32, _I32, C.c_double, C.c_uint64, _P],
+    "ac_mpt_mask": [_P, _P, _P, _I32, _I32, C.c_double, C.c_uint64, _P, _P],
     "ac_mpt_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _F, _F, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ac_colsum_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
@@ -101,7 +101,7 @@ SIGNATURES = {
     "ac_gather_cols": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
     "ac_gate_fwd": [_P, _P, _P, _P, _I64, _P],
     "ac_gate_bwd": [_P, _P, _P, _P, _P, _I64, _P],
-    "ac_dropout": [_P, _P, _I64, _F, _U64, _U64, _P],
+    "ac_dropout": [_P, _P, _I64, _F, _U64, _U64, _P, _P],
     "ac_layerscale_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "ac_add": [_P, _P, _P, _I64, _F, _P],
     "ac_scale_by_dev": [_P, _I64, _P, _P],
@@ -120,14 +120,14 @@ SIGNATURES = {
     "ac_toeplitz_fold": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_embed_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
-    "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
-    "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P],
+    "ac_mha_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _P],
+    "ac_mha_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _P],
     "ac_batchnorm_fwd": [_P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _F, _I32, _I32, _P],
     "ac_batchnorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ac_conv1d_window_x3": [C.POINTER(ConvWinDesc), _P],
     "ac_conv1d_wgrad_bf16": [C.POINTER(WgradDesc), _P],
-    "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
-    "ac_mha_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _I32, _P],
+    "ac_mha_fwd_mfma": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _I32, _P],
+    "ac_mha_bwd_mfma": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _I32, _P],
     "ac_split_bf16": [_P, _P, _P, _I64, _P],
     "ac_transpose_split_bf16": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
     "ac_pad_rows_split": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
@@ -139,12 +139,12 @@ SIGNATURES = {
     "ac_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _P],
     "ac_adam_flat": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _I32, _P, _P],
     "ac_adam_flat_dev": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _P, _P, _P],
-    "ac_set_step_counter": [_P],
     "ac_step_advance": [_P, _P],
     "ac_sgd_flat": [_P, _P, _P, _I64, _F, _F, _F, _I32, _P],
     "ac_sumsq": [_P, _I64, _P, _P],
     "ac_clip_coef": [_P, _F, _P, _P],
 }
+ABI_VERSION = 2
 _RESTYPES = {"ac_strerror": C.c_char_p}
 
 _lib = None
@@ -166,8 +166,9 @@ def _load_path(path: str):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.ac_abi_version() != 1:
-        raise HipLibraryMissing(f"ABI version mismatch: {lib.ac_abi_version()} != 1")
+    if lib.ac_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"ABI version mismatch: {lib.ac_abi_version()} != {ABI_VERSION} (rebuild: "
+                                "make -C applecider_amd/csrc)")
     return lib
 
 

@@ -465,28 +465,29 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
 
 template <bool SPLIT, bool DROP>
 int launch_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int B, int T, int H, float p,
-               uint64_t seed, hipStream_t st) {
+               uint64_t seed, const uint64_t *step, hipStream_t st) {
     const int Tp = (T + 31) & ~31;
     const size_t lds = (size_t)(SPLIT ? 4 : 2) * Tp * 32 + Tp;
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_fwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
     hipLaunchKernelGGL((mha_fwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_FWD), lds, st, qkv, pad, out, lse, T,
-                       H, p, seed, ac_step_ptr());
+                       H, p, seed, step);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
 
 template <bool SPLIT, bool DROP>
 int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const float *out, const float *lse,
-               float *dqkv, int B, int T, int H, float p, uint64_t seed, hipStream_t st) {
+               float *dqkv, int B, int T, int H, float p, uint64_t seed, const uint64_t *step,
+               hipStream_t st) {
     const int Tp = (T + 31) & ~31;
     const size_t lds = (size_t)(SPLIT ? 8 : 4) * Tp * 32 + 2 * Tp * sizeof(float) + Tp;
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_bwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
     hipLaunchKernelGGL((mha_bwd_mfma_kernel<SPLIT, DROP>), dim3(B * H), dim3(ATT_NT_BWD), lds, st, dout, qkv, pad, out,
-                       lse, dqkv, T, H, p, seed, ac_step_ptr());
+                       lse, dqkv, T, H, p, seed, step);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -494,7 +495,7 @@ int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
 }  // namespace
 
 extern "C" int ac_mha_fwd_mfma(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B,
-                               int32_t T, int32_t H, int32_t Dh, float p_drop, uint64_t seed, int32_t split,
+                               int32_t T, int32_t H, int32_t Dh, float p_drop, uint64_t seed, const uint64_t *step, int32_t split,
                                ac_stream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0) return AC_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f) return AC_EINVAL;
@@ -502,23 +503,23 @@ extern "C" int ac_mha_fwd_mfma(const float *qkv, const uint8_t *pad, float *out,
     if (!ac_aligned16(qkv)) return AC_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const bool drop = p_drop > 0.f;
-    if (split) return drop ? launch_fwd<true, true>(qkv, pad, out, lse, B, T, H, p_drop, seed, st)
-                           : launch_fwd<true, false>(qkv, pad, out, lse, B, T, H, p_drop, seed, st);
-    return drop ? launch_fwd<false, true>(qkv, pad, out, lse, B, T, H, p_drop, seed, st)
-                : launch_fwd<false, false>(qkv, pad, out, lse, B, T, H, p_drop, seed, st);
+    if (split) return drop ? launch_fwd<true, true>(qkv, pad, out, lse, B, T, H, p_drop, seed, step, st)
+                           : launch_fwd<true, false>(qkv, pad, out, lse, B, T, H, p_drop, seed, step, st);
+    return drop ? launch_fwd<false, true>(qkv, pad, out, lse, B, T, H, p_drop, seed, step, st)
+                : launch_fwd<false, false>(qkv, pad, out, lse, B, T, H, p_drop, seed, step, st);
 }
 
 extern "C" int ac_mha_bwd_mfma(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
                                const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
-                               float p_drop, uint64_t seed, int32_t split, ac_stream_t stream) {
+                               float p_drop, uint64_t seed, const uint64_t *step, int32_t split, ac_stream_t stream) {
     if (!dout || !qkv || !out || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return AC_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f) return AC_EINVAL;
     if (Dh != 16 || T > ATT_TMAX) return AC_EINVAL;
     if (!ac_aligned16(qkv) || !ac_aligned16(dout) || !ac_aligned16(out) || !ac_aligned16(dqkv)) return AC_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const bool drop = p_drop > 0.f;
-    if (split) return drop ? launch_bwd<true, true>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, st)
-                           : launch_bwd<true, false>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, st);
-    return drop ? launch_bwd<false, true>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, st)
-                : launch_bwd<false, false>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, st);
+    if (split) return drop ? launch_bwd<true, true>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, step, st)
+                           : launch_bwd<true, false>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, step, st);
+    return drop ? launch_bwd<false, true>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, step, st)
+                : launch_bwd<false, false>(dout, qkv, pad, out, lse, dqkv, B, T, H, p_drop, seed, step, st);
 }

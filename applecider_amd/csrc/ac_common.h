@@ -133,11 +133,11 @@ __device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
     return (float)(ac_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
 
-// Device-resident step counter (ac_set_step_counter): when one is registered every dropout / mask
-// generator mixes it into the seed its launch was given, so a captured hipGraph of a whole training
-// step draws a new mask at every replay (the host-side seed baked into the graph stays the same;
-// ac_step_advance bumps the counter inside the graph).  Null: seeds are used as given.
-const uint64_t *ac_step_ptr();   // host side, defined in ac_optim.hip
+// Device-resident step counter: every entry point that draws random numbers takes an optional
+// `step` pointer (uint64 in HBM) and mixes step[0] into the seed its launch was given, so a captured
+// hipGraph of a whole training step draws a new mask at every replay (the host-side seed baked into
+// the graph stays the same; ac_step_advance bumps the counter inside the graph).  Null: the seed is
+// used as given; a counter at 0 likewise.
 __device__ __forceinline__ uint64_t ac_step_seed(uint64_t seed, const uint64_t *stepp) {
     return stepp ? seed + stepp[0] * 0x9E3779B97F4A7C15ull : seed;
 }

@@ -487,12 +487,11 @@ extern "C" int ac_gate_bwd(const float *dout, const float *a, const float *g, fl
     EW_LAUNCH(gate_bwd_kernel, n, dout, a, g, da, dg, n);
 }
 extern "C" int ac_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed,
-                          uint64_t offset, ac_stream_t stream) {
+                          uint64_t offset, const uint64_t *step, ac_stream_t stream) {
     if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return AC_EINVAL;
     if (n % 4 == 0 && ac_aligned16(x) && ac_aligned16(y))
-        EW_LAUNCH(dropout_vec_kernel, n / 4, x, y, n / 4, p, 1.0f / (1.0f - p), seed, offset,
-                  ac_step_ptr());
-    EW_LAUNCH(dropout_kernel, n, x, y, n, p, 1.0f / (1.0f - p), seed, offset, ac_step_ptr());
+        EW_LAUNCH(dropout_vec_kernel, n / 4, x, y, n / 4, p, 1.0f / (1.0f - p), seed, offset, step);
+    EW_LAUNCH(dropout_kernel, n, x, y, n, p, 1.0f / (1.0f - p), seed, offset, step);
 }
 extern "C" int ac_add(const float *a, const float *b, float *y, int64_t n, float alpha,
                       ac_stream_t stream) {

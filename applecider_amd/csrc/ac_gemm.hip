@@ -34,7 +34,6 @@ struct GemmParams {
     int tiles_m, tiles_n, nkt, kt_per_split;
     int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
     int epi_var;  // compile-time epilogue variant (AC_EPI_VARIANTS index) or EPI_GENERIC
-    const uint64_t *stepp;  // ac_set_step_counter()'s device counter (or null): mixed into drop_seed
 };
 
 // round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
@@ -420,7 +419,7 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm16 = reinterpret_cast<unsigned short *>(smem);
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -877,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     constexpr int B_IMG = B_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -1011,7 +1010,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm = reinterpret_cast<unsigned short *>(smem);
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -1246,7 +1245,7 @@ __global__ __launch_bounds__(256) void transpose_cast_segments_kernel(
 // ---------------------------------------------------------------------------
 __global__ void gemm_simple_kernel(GemmParams p) {
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)d.M * d.N) return;
     int m = (int)(idx / d.N), n = (int)(idx % d.N);
@@ -1272,7 +1271,7 @@ __global__ void gemm_simple_kernel(GemmParams p) {
 // one wave per output element, lanes stride the reduction, shuffle-reduce.
 __global__ __launch_bounds__(256) void gemm_simple_tn_wave_kernel(GemmParams p) {
     const ac_gemm_desc &d = p.d;
-    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.stepp);
+    const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (widx >= (int64_t)d.M * d.N) return;
     const int lane = threadIdx.x & 63;
@@ -1361,7 +1360,6 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
             return AC_EALIGN;
         GemmParams p;
         p.d = d;
-        p.stepp = ac_step_ptr();
         if (d.split_k > 1) p.d.accumulate = 2;
         if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
         if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
@@ -1395,7 +1393,6 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
 
     GemmParams p;
     p.d = d;
-    p.stepp = ac_step_ptr();
     if (!use_mfma) {
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.

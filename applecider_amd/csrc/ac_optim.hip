@@ -87,20 +87,11 @@ inline int stream_grid(int64_t n) {
     return (int)g;
 }
 
-const uint64_t *g_step_counter = nullptr;
-
 int adam_launch(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                 const ac_adam_seg *segs, int32_t nseg, int32_t step, const int64_t *step_dev,
                 const float *grad_scale_dev, ac_stream_t stream);
 
 }  // namespace
-
-const uint64_t *ac_step_ptr() { return g_step_counter; }
-
-extern "C" int ac_set_step_counter(const uint64_t *counter_dev) {
-    g_step_counter = counter_dev;
-    return AC_OK;
-}
 
 extern "C" int ac_step_advance(uint64_t *counter_dev, ac_stream_t stream) {
     if (!counter_dev) return AC_EINVAL;

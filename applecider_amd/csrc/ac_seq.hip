@@ -425,7 +425,7 @@ extern "C" int ac_embed_bwd(const float *dh, const float *x, const float *tw, co
 
 extern "C" int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B,
                           int32_t T, int32_t H, int32_t Dh, float p_drop, uint64_t seed,
-                          ac_stream_t stream) {
+                          const uint64_t *step, ac_stream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0) return AC_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f) return AC_EINVAL;
     const size_t lds = ((size_t)2 * T * Dh + T) * sizeof(float);
@@ -433,10 +433,10 @@ extern "C" int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, floa
     dim3 grid(B * H);
     if (Dh == 16)
         hipLaunchKernelGGL(mha_fwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, pad,
-                           out, lse, T, H, p_drop, seed, ac_step_ptr());
+                           out, lse, T, H, p_drop, seed, step);
     else if (Dh == 32)
         hipLaunchKernelGGL(mha_fwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, qkv, pad,
-                           out, lse, T, H, p_drop, seed, ac_step_ptr());
+                           out, lse, T, H, p_drop, seed, step);
     else
         return AC_EINVAL;
     AC_CHECK_LAUNCH();
@@ -445,7 +445,8 @@ extern "C" int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, floa
 
 extern "C" int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad,
                           const float *out, const float *lse, float *dqkv, int32_t B, int32_t T,
-                          int32_t H, int32_t Dh, float p_drop, uint64_t seed, ac_stream_t stream) {
+                          int32_t H, int32_t Dh, float p_drop, uint64_t seed, const uint64_t *step,
+                          ac_stream_t stream) {
     if (!dout || !qkv || !out || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return AC_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f) return AC_EINVAL;
     const size_t lds = ((size_t)2 * T * Dh + 3 * T) * sizeof(float);
@@ -453,10 +454,10 @@ extern "C" int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pa
     dim3 grid(B * H);
     if (Dh == 16)
         hipLaunchKernelGGL(mha_bwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, dout, qkv,
-                           pad, out, lse, dqkv, T, H, p_drop, seed, ac_step_ptr());
+                           pad, out, lse, dqkv, T, H, p_drop, seed, step);
     else if (Dh == 32)
         hipLaunchKernelGGL(mha_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, dout, qkv,
-                           pad, out, lse, dqkv, T, H, p_drop, seed, ac_step_ptr());
+                           pad, out, lse, dqkv, T, H, p_drop, seed, step);
     else
         return AC_EINVAL;
     AC_CHECK_LAUNCH();
@@ -464,11 +465,11 @@ extern "C" int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pa
 }
 
 extern "C" int ac_mpt_mask(float *x, const uint8_t *pad, uint8_t *masked, int32_t B, int32_t L,
-                           double mask_p, uint64_t seed, ac_stream_t stream) {
+                           double mask_p, uint64_t seed, const uint64_t *step, ac_stream_t stream) {
     if (!x || !pad || !masked || B <= 0 || L <= 0 || L > MPT_MAXL || mask_p < 0.0 || mask_p > 1.0)
         return AC_EINVAL;
     hipLaunchKernelGGL(mpt_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, pad, masked, L,
-                       mask_p, seed, ac_step_ptr());
+                       mask_p, seed, step);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

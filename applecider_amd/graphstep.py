@@ -7,8 +7,9 @@ fork / join events become graph edges) and replays it with one launch per step.
 
 What makes the captured step a *training* step and not a replay of the same one:
   * dropout / attention-dropout / masking seeds: the host seeds baked into the captured launches are mixed
-    on the device with a step counter in HBM (`hipops.enable_device_step`, `ac_set_step_counter`), which
-    the graph itself advances first thing every replay;
+    on the device with a step counter in HBM (`hipops.enable_device_step`; the `step` argument of
+    ac_dropout / ac_mha_* / ac_mpt_mask and `ac_gemm_desc.drop_step`), which the graph itself advances
+    first thing every replay (`ac_step_advance`);
   * Adam's bias corrections: `FlatAdam.set_capturable()` keeps the step count in HBM as well
     (`ac_adam_flat_dev`), advanced inside the graph;
   * the batch: copied into static input tensors before each replay (device-to-device, or straight from the

@@ -50,8 +50,6 @@ def set_math(mode: str):
         _MATH_EPOCH += 1
         _step_cache.clear()
     _MODE = mode
-    if _STEP_DEV is not None:   # the library variant selected now must know the step counter too
-        _lib.check(_lib_().ac_set_step_counter(_p(_STEP_DEV)), "ac_set_step_counter")
 
 
 def get_math() -> str:
@@ -141,6 +139,7 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     d.c16, d.ld_c16 = _p(c16), ld_c16
     d.mask16, d.ld_mask16 = _p(mask16), ld_mask16
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
+    d.drop_step = _p(_STEP_DEV) if drop_p > 0.0 else None
     _lib.check(_lib_().ac_gemm(C.byref(d), _stream()), "ac_gemm")
 
 
@@ -534,23 +533,20 @@ _STEP_DEV = None
 
 
 def enable_device_step(device=None) -> torch.Tensor:
-    """Registers a device-resident step counter with the library (ac_set_step_counter): from now on every
-    dropout / mask generator mixes counter[0] into the seed its launch carries, so a captured hipGraph
-    of a training step draws new masks at every replay.  Advance it once per step with step_advance()
-    (GraphedTrainStep does).  Returns the counter (int64[1]; the kernels read it as uint64)."""
+    """Creates the device-resident step counter of this process: from now on every dropout / mask launch
+    is handed its address (the `step` argument of ac_dropout / ac_mha_* / ac_mpt_mask, ac_gemm_desc.drop_step)
+    and mixes counter[0] into the seed it carries, so a captured hipGraph of a training step draws new
+    masks at every replay.  Advance it once per step with step_advance() (GraphedTrainStep does).
+    Returns the counter (int64[1]; the kernels read it as uint64)."""
     global _STEP_DEV
     if _STEP_DEV is None:
         _STEP_DEV = torch.zeros(1, dtype=torch.int64, device=device or torch.device("cuda", torch.cuda.current_device()))
-    _lib.check(_lib_().ac_set_step_counter(_p(_STEP_DEV)), "ac_set_step_counter")
     return _STEP_DEV
 
 
 def disable_device_step():
-    """Back to plain host seeds (every loaded library variant)."""
+    """Back to plain host seeds."""
     global _STEP_DEV
-    if _STEP_DEV is not None:
-        for lib in _lib.loaded():
-            _lib.check(lib.ac_set_step_counter(None), "ac_set_step_counter")
     _STEP_DEV = None
 
 
@@ -761,7 +757,7 @@ class _MLP(Function):
         g2 = dy2
         if ctx.p2 > 0:
             g2 = torch.empty_like(dy2)
-            _lib.check(lib.ac_dropout(_p(dy2), _p(g2), M * N, ctx.p2, ctx.seed2, 0, st), "ac_dropout")
+            _lib.check(lib.ac_dropout(_p(dy2), _p(g2), M * N, ctx.p2, ctx.seed2, 0, _p(_STEP_DEV), st), "ac_dropout")
         dcs = db2 = None
         b2sink = _sink(b2p) if (b2p is not None and ctx.needs_input_grad[4]) else None
         g2_16 = torch.empty(M, N, device=dev, dtype=_H16)
@@ -966,7 +962,7 @@ class _Dropout(Function):
     def forward(ctx, x, p, seed):
         x = _chk(x, "x")
         y = torch.empty_like(x)
-        _lib.check(_lib_().ac_dropout(_p(x), _p(y), x.numel(), p, seed, 0, _stream()), "ac_dropout")
+        _lib.check(_lib_().ac_dropout(_p(x), _p(y), x.numel(), p, seed, 0, _p(_STEP_DEV), _stream()), "ac_dropout")
         ctx.p, ctx.seed = p, seed
         return y
 
@@ -974,7 +970,7 @@ class _Dropout(Function):
     def backward(ctx, dy):
         dy = _chk(dy, "dy")
         dx = torch.empty_like(dy)
-        _lib.check(_lib_().ac_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, 0, _stream()),
+        _lib.check(_lib_().ac_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, 0, _p(_STEP_DEV), _stream()),
                    "ac_dropout")
         return dx, None, None
 
@@ -1760,10 +1756,10 @@ class _MHA(Function):
         split = 1 if _MATH == _lib.MATH_BF16X3 else 0
         if mfma:
             _lib.check(_lib_().ac_mha_fwd_mfma(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
-                                               seed, split, _stream()), "ac_mha_fwd_mfma")
+                                               seed, _p(_STEP_DEV), split, _stream()), "ac_mha_fwd_mfma")
         else:
             _lib.check(_lib_().ac_mha_fwd(_p(qkv), _p(pad_u8), _p(out), _p(lse), B, T, H, Dh, p_drop,
-                                          seed, _stream()), "ac_mha_fwd")
+                                          seed, _p(_STEP_DEV), _stream()), "ac_mha_fwd")
         ctx.save_for_backward(qkv, pad_u8, out, lse)
         ctx.cfg = (B, T, H, Dh, p_drop, seed)
         ctx.mfma, ctx.split = mfma, split
@@ -1777,11 +1773,11 @@ class _MHA(Function):
         dqkv = torch.empty_like(qkv)
         if ctx.mfma:
             _lib.check(_lib_().ac_mha_bwd_mfma(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
-                                               T, H, Dh, p_drop, seed, ctx.split, _stream()),
+                                               T, H, Dh, p_drop, seed, _p(_STEP_DEV), ctx.split, _stream()),
                        "ac_mha_bwd_mfma")
         else:
             _lib.check(_lib_().ac_mha_bwd(_p(dout), _p(qkv), _p(pad_u8), _p(out), _p(lse), _p(dqkv), B,
-                                          T, H, Dh, p_drop, seed, _stream()), "ac_mha_bwd")
+                                          T, H, Dh, p_drop, seed, _p(_STEP_DEV), _stream()), "ac_mha_bwd")
         return dqkv, None, None, None, None
 
 
@@ -1938,7 +1934,8 @@ def mpt_mask(data: torch.Tensor, pad: torch.Tensor, mask_p: float, seed: Optiona
     pad_u8 = pad.to(torch.uint8).contiguous()
     masked = torch.empty(B, L, device=data.device, dtype=torch.uint8)
     _lib.check(_lib_().ac_mpt_mask(_p(data), _p(pad_u8), _p(masked), B, L, float(mask_p),
-                                   next_seed() if seed is None else int(seed), _stream()), "ac_mpt_mask")
+                                   next_seed() if seed is None else int(seed), _p(_STEP_DEV), _stream()),
+               "ac_mpt_mask")
     return masked.bool()
 
 

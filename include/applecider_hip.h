@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AC_ABI_VERSION 1
+#define AC_ABI_VERSION 2
 
 #define AC_OK 0
 #define AC_EINVAL (-22)     /* bad argument / unsupported shape            */
@@ -130,6 +130,7 @@ typedef struct ac_gemm_desc {
     int64_t ld_mask16;
     float drop_p;         /* 0: no dropout */
     uint64_t drop_seed;
+    const uint64_t *drop_step; /* nullable DEVICE counter mixed into drop_seed (see ac_step_advance) */
 } ac_gemm_desc;
 
 int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);
@@ -246,9 +247,10 @@ int ac_gate_fwd(const float *a, const float *g, const float *s, float *out, int6
 /* da = dout*g, dg = dout*a. */
 int ac_gate_bwd(const float *dout, const float *a, const float *g, float *da, float *dg,
                 int64_t n, ac_stream_t stream);
-/* y = x * keep(seed, offset + i) / (1-p); the same call with dy gives dx (nn.Dropout). */
+/* y = x * keep(seed', offset + i) / (1-p); the same call with dy gives dx (nn.Dropout).
+ * seed' = seed when step is NULL, else seed + step[0] * 0x9E3779B97F4A7C15 (ac_step_advance). */
 int ac_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
-               ac_stream_t stream);
+               const uint64_t *step, ac_stream_t stream);
 /* ConvNeXt layer-scale backward: dyl = dy*gamma[n] (fp32 and/or bf16 copy, either nullable);
  * dgamma[n] += sum_m dy*ylin; dbias[n] (nullable) += sum_m dyl = the bias gradient of the linear
  * layer under the scale (atomics: zero dgamma / dbias first). */
@@ -328,10 +330,10 @@ int ac_embed_bwd(const float *dh, const float *x, const float *tw, const float *
  * attention probabilities with the counter RNG. */
 int ac_mha_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B,
                int32_t T, int32_t H, int32_t Dh, float p_drop, uint64_t seed,
-               ac_stream_t stream);
+               const uint64_t *step, ac_stream_t stream);
 int ac_mha_bwd(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
                const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
-               float p_drop, uint64_t seed, ac_stream_t stream);
+               float p_drop, uint64_t seed, const uint64_t *step, ac_stream_t stream);
 
 /* BatchNorm1d over the columns of a [rows, cols] channels-last tensor (rows = B*L positions) fused with
  * an activation: SpectraNetBlock with use_ln = False (spectranet.py:21,33-37).  training != 0: batch
@@ -375,10 +377,11 @@ int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *d, ac_stream_t stream);
  * ac_mha_fwd / ac_mha_bwd.  Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer
  * (HyraxBaselineCLS.py:24-31,73-79). */
 int ac_mha_fwd_mfma(const float *qkv, const uint8_t *pad, float *out, float *lse, int32_t B, int32_t T,
-                    int32_t H, int32_t Dh, float p_drop, uint64_t seed, int32_t split, ac_stream_t stream);
+                    int32_t H, int32_t Dh, float p_drop, uint64_t seed, const uint64_t *step, int32_t split,
+                    ac_stream_t stream);
 int ac_mha_bwd_mfma(const float *dout, const float *qkv, const uint8_t *pad, const float *out,
                     const float *lse, float *dqkv, int32_t B, int32_t T, int32_t H, int32_t Dh,
-                    float p_drop, uint64_t seed, int32_t split, ac_stream_t stream);
+                    float p_drop, uint64_t seed, const uint64_t *step, int32_t split, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Towers / MoE / fusion head (astrominn.py:264-295; _archive core/model.py:40-67).
@@ -421,7 +424,7 @@ int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha,
  * gradient); outputs: loss (1 float), df, db, ddt in the same shapes.  sums: 4 floats of scratch.
  * ---------------------------------------------------------------------- */
 int ac_mpt_mask(float *x, const uint8_t *pad, uint8_t *masked, int32_t B, int32_t L, double mask_p,
-                uint64_t seed, ac_stream_t stream);
+                uint64_t seed, const uint64_t *step, ac_stream_t stream);
 int ac_mpt_loss_fwd_bwd(const float *f_hat, const float *b_hat, const float *dt_hat,
                         const float *data, const uint8_t *masked, float *sums, float *loss, float *df,
                         float *db, float *ddt, int32_t B, int32_t L, float lambda_f, float lambda_b,
@@ -454,15 +457,15 @@ int ac_sgd_flat(float *param, const float *grad, float *momentum_buf, int64_t n,
                 float momentum, float weight_decay, int32_t first_step, ac_stream_t stream);
 /* Device-resident step counter for graph capture.
  *   ac_step_advance(counter, stream): counter[0] += 1 on the stream (one tiny kernel).
- *   ac_set_step_counter(counter | NULL): registers a counter with the library; from then on every
- *   random generator on the path (ac_dropout, the GEMM epilogue's dropout, ac_mha_* attention
- *   dropout, ac_mpt_mask) uses seed' = seed + counter[0] * 0x9E3779B97F4A7C15 instead of the seed
- *   its launch was given.  Forward and backward of one step read the same counter value, so their
- *   masks agree; a replayed graph (same host seeds) draws new masks once the counter advanced.
- *   The replacement for torch's philox (seed, offset) pair kept on the device by CUDA graphs
- *   (nn.Dropout / MultiheadAttention dropout: photo_events.py:55-64, HyraxBaselineCLS.py:31).
- *   NULL (default) restores plain host seeds.  Process-wide, not thread-safe. */
-int ac_set_step_counter(const uint64_t *counter_dev);
+ *   Every entry point that draws random numbers (ac_dropout, ac_gemm's epilogue dropout through
+ *   ac_gemm_desc.drop_step, ac_mha_* attention dropout, ac_mpt_mask) takes a nullable `step` pointer to
+ *   such a counter and uses seed' = seed + step[0] * 0x9E3779B97F4A7C15 instead of the seed its launch
+ *   was given (a counter at 0 and a NULL pointer are the same thing).  Forward and backward of one
+ *   training step read the same counter value, so their masks agree; a replayed hipGraph (same host
+ *   seeds baked in) draws new masks once the counter advanced.  The library keeps no state: the
+ *   counter is the caller's.  This is what torch's philox (seed, offset) pair kept on the device does
+ *   for CUDA graphs (nn.Dropout / MultiheadAttention dropout: photo_events.py:55-64,
+ *   HyraxBaselineCLS.py:31). */
 int ac_step_advance(uint64_t *counter_dev, ac_stream_t stream);
 /* out[0] = sum x^2 (zeroed by the call); clip coefficient computed on device:
  * coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)). */
