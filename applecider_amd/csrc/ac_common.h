@@ -31,6 +31,8 @@ __device__ __forceinline__ unsigned short ac_f2h(float x) {
 __device__ __forceinline__ float ac_h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 #define AC_MFMA16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ac_h8, a), __builtin_bit_cast(ac_h8, b), c, 0, 0, 0)
+#define AC_MFMA16S(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ac_h8, a), __builtin_bit_cast(ac_h8, b), c, 0, 0, 0)
 #define AC_HALF_NAME "f16"
 #else
 __device__ __forceinline__ unsigned short ac_f2h(float x) {
@@ -38,6 +40,9 @@ __device__ __forceinline__ unsigned short ac_f2h(float x) {
 }
 __device__ __forceinline__ float ac_h2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 #define AC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// 16x16x32 shape (16 cycles): lane l holds A[row l&15][k = 8(l>>4)..+7], B[k = 8(l>>4)..+7][col l&15],
+// D[row 4(l>>4)+e][col l&15].  Same FLOP per cycle as 32x32x16; the chip holds a higher clock on it.
+#define AC_MFMA16S(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define AC_HALF_NAME "bf16"
 #endif
 

@@ -479,7 +479,7 @@ int launch_ks2(ConvWinParams &p, hipStream_t stream) {
 // stay in registers.  TC is chosen by the host so that the chunk fits the 160 KB LDS (k = 251 at
 // 64 channels: two chunks of 129 + 122 taps).
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN>
+template <int WM, int WN, bool S16>
 __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWinParams p, int TC) {
     constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, CC = 64;
     constexpr int BCH = BN * 8 / NT;          // weight chunks per thread per plane per K tile
@@ -517,13 +517,19 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
         wbase[i] = (int64_t)n * d.w_row_stride + 8 * (t & 7);
     }
 
-    f32x16 acc[2][2];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 acc[2][2];      // 32x32x16 form: [row half][column half] of the wave's 64 x 64 tile
+    f32x4 acs[4][4];       // 16x16x32 form (S16): [16-row block][16-column block]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int cchunks = d.C / CC;
     for (int cch = 0; cch < cchunks; ++cch) {
@@ -560,32 +566,115 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                     *(u32x4 *)(stage + WT + off) = v[BCH + i];
                 }
             };
-            auto compute = [&](int kt, const unsigned short *bt) {
+            // One K tile (one tap x 64 channels) = 4 steps of 16 channels; the operand reads of step s + 1
+            // are issued ahead of the 12 MFMAs of step s (register double buffer, pinned by sched_barriers:
+            // left alone the scheduler sinks every read to just before its first use), so only step 0's
+            // reads are exposed.
+            // 16x16x32 form of the same tile: a K tile = 2 steps of 32 channels; per step the wave reads its
+            // 8 B fragments (4 column blocks x (hi, lo)) once and walks the 4 row blocks in two halves, the
+            // next half's A fragments / next step's B fragments in flight under the 24 MFMAs of this half.
+            auto compute16 = [&](int kt, const unsigned short *bt) {
+                const int lr = lane & 15, g = lane >> 4;
+                int ar[4], bo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = wm * 64 + 16 * i + lr;
+                    ar[i] = (m >> lsh) * wr + (m & (Ls - 1)) + kt;
+                    bo[i] = wn * 64 + 16 * i + lr;
+                }
+                bf16x8 Bf[2][8], Af[2][4];   // Bf: [hi j0..3 | lo j0..3] ; Af: [hi i0 i1 | lo i0 i1] of one half
+                auto ldB = [&](int s2, bf16x8 (&Bv)[8]) {
+                    const int cc = 4 * s2 + g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o = bo[j] * 64 + ((cc ^ ((bo[j] >> 1) & 7)) << 3);
+                        Bv[j] = *(const bf16x8 *)(bt + o);
+                        Bv[4 + j] = *(const bf16x8 *)(bt + WT + o);
+                    }
+                };
+                auto ldA = [&](int s2, int h, bf16x8 (&A)[4]) {
+                    const int cc = 4 * s2 + g;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int o = win_off<64>(ar[2 * h + i], cc);
+                        A[i] = *(const bf16x8 *)(win_h + o);
+                        A[2 + i] = *(const bf16x8 *)(win_l + o);
+                    }
+                };
+                auto mm = [&](int h, const bf16x8 (&A)[4], const bf16x8 (&Bv)[8]) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[2 + i], Bv[j], acs[2 * h + i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[i], Bv[4 + j], acs[2 * h + i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[i], Bv[j], acs[2 * h + i][j]);
+                };
+                ldB(0, Bf[0]);
+                ldA(0, 0, Af[0]);
+                ldA(0, 1, Af[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(0, Af[0], Bf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                ldB(1, Bf[1]);
+                ldA(1, 0, Af[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(1, Af[1], Bf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                ldA(1, 1, Af[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(0, Af[0], Bf[1]);
+                mm(1, Af[1], Bf[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto compute32 = [&](int kt, const unsigned short *bt) {
                 const int m0 = wm * 64 + li, m1 = m0 + 32;   // tile rows -> (sample, position) -> window rows
                 const int r0 = (m0 >> lsh) * wr + (m0 & (Ls - 1)) + kt, r1 = (m1 >> lsh) * wr + (m1 & (Ls - 1)) + kt;
                 const int n0 = wn * 64 + li, n1 = n0 + 32;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cc = 2 * s + lh;
+                bf16x8 fa[2][4], fb[2][4];   // [buffer][a0h a1h a0l a1l] / [b0h b1h b0l b1l]
+                auto ld = [&](int s_, bf16x8 (&A)[4], bf16x8 (&Bv)[4]) {
+                    const int cc = 2 * s_ + lh;
                     const int ao0 = win_off<64>(r0, cc), ao1 = win_off<64>(r1, cc);
                     const int bo0 = n0 * 64 + ((cc ^ ((n0 >> 1) & 7)) << 3), bo1 = n1 * 64 + ((cc ^ ((n1 >> 1) & 7)) << 3);
-                    const bf16x8 a0h = *(const bf16x8 *)(win_h + ao0), a1h = *(const bf16x8 *)(win_h + ao1);
-                    const bf16x8 b0h = *(const bf16x8 *)(bt + bo0), b1h = *(const bf16x8 *)(bt + bo1);
-                    const bf16x8 a0l = *(const bf16x8 *)(win_l + ao0), a1l = *(const bf16x8 *)(win_l + ao1);
-                    const bf16x8 b0l = *(const bf16x8 *)(bt + WT + bo0), b1l = *(const bf16x8 *)(bt + WT + bo1);
-                    acc[0][0] = AC_MFMA16(a0l, b0h, acc[0][0]);
-                    acc[0][1] = AC_MFMA16(a0l, b1h, acc[0][1]);
-                    acc[1][0] = AC_MFMA16(a1l, b0h, acc[1][0]);
-                    acc[1][1] = AC_MFMA16(a1l, b1h, acc[1][1]);
-                    acc[0][0] = AC_MFMA16(a0h, b0l, acc[0][0]);
-                    acc[0][1] = AC_MFMA16(a0h, b1l, acc[0][1]);
-                    acc[1][0] = AC_MFMA16(a1h, b0l, acc[1][0]);
-                    acc[1][1] = AC_MFMA16(a1h, b1l, acc[1][1]);
-                    acc[0][0] = AC_MFMA16(a0h, b0h, acc[0][0]);
-                    acc[0][1] = AC_MFMA16(a0h, b1h, acc[0][1]);
-                    acc[1][0] = AC_MFMA16(a1h, b0h, acc[1][0]);
-                    acc[1][1] = AC_MFMA16(a1h, b1h, acc[1][1]);
+                    A[2] = *(const bf16x8 *)(win_l + ao0);
+                    A[3] = *(const bf16x8 *)(win_l + ao1);
+                    Bv[0] = *(const bf16x8 *)(bt + bo0);
+                    Bv[1] = *(const bf16x8 *)(bt + bo1);
+                    A[0] = *(const bf16x8 *)(win_h + ao0);
+                    A[1] = *(const bf16x8 *)(win_h + ao1);
+                    Bv[2] = *(const bf16x8 *)(bt + WT + bo0);
+                    Bv[3] = *(const bf16x8 *)(bt + WT + bo1);
+                };
+                ld(0, fa[0], fb[0]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8(&A)[4] = fa[s & 1];
+                    const bf16x8(&Bv)[4] = fb[s & 1];
+                    if (s < 3) ld(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // reads of step s + 1 are in flight before step s's MFMAs
+                    acc[0][0] = AC_MFMA16(A[2], Bv[0], acc[0][0]);
+                    acc[0][1] = AC_MFMA16(A[2], Bv[1], acc[0][1]);
+                    acc[1][0] = AC_MFMA16(A[3], Bv[0], acc[1][0]);
+                    acc[1][1] = AC_MFMA16(A[3], Bv[1], acc[1][1]);
+                    acc[0][0] = AC_MFMA16(A[0], Bv[2], acc[0][0]);
+                    acc[0][1] = AC_MFMA16(A[0], Bv[3], acc[0][1]);
+                    acc[1][0] = AC_MFMA16(A[1], Bv[2], acc[1][0]);
+                    acc[1][1] = AC_MFMA16(A[1], Bv[3], acc[1][1]);
+                    acc[0][0] = AC_MFMA16(A[0], Bv[0], acc[0][0]);
+                    acc[0][1] = AC_MFMA16(A[0], Bv[1], acc[0][1]);
+                    acc[1][0] = AC_MFMA16(A[1], Bv[0], acc[1][0]);
+                    acc[1][1] = AC_MFMA16(A[1], Bv[1], acc[1][1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            auto compute = [&](int kt, const unsigned short *bt) {
+                if constexpr (S16) compute16(kt, bt);
+                else compute32(kt, bt);
             };
             unsigned short *S0 = bst, *S1 = bst + 2 * WT;
             const int last = tc - 1;
@@ -616,16 +705,25 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     float *wbuf = smem + wave * 2048;
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = tn * BN + wn * 64 + c4;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (d.bias && n < d.N) bias4 = *(const f32x4 *)(d.bias + n);
 #pragma unroll
     for (int sa = 0; sa < 2; ++sa) {
+        if constexpr (S16) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            wbuf[r * 64 + li] = acc[sa][0][e];
-            wbuf[r * 64 + 32 + li] = acc[sa][1][e];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        wbuf[(16 * i + 4 * (lane >> 4) + e) * 64 + 16 * j + (lane & 15)] = acs[2 * sa + i][j][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                wbuf[r * 64 + li] = acc[sa][0][e];
+                wbuf[r * 64 + 32 + li] = acc[sa][1][e];
+            }
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -641,8 +739,9 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool S16 = true>
 int launch_x3(ConvWinParams &p, hipStream_t stream) {
+    if (S16 && p.d.variant == 2) return launch_x3<WM, WN, false>(p, stream);   // variant 2: the 32x32x16 form
     constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
     const ac_convwin_desc &d = p.d;
     const size_t stages = (size_t)2 * 2 * BN * 64 * sizeof(short);
@@ -659,13 +758,13 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
     p.vec_epi = 1;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3_kernel<WM, WN>,
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3_kernel<WM, WN, S16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
     const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
-    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
+    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

@@ -25,8 +25,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_TAPS = 8, WG_KP = 64, WG_CO = 128, WG_CI = 64;
-constexpr int A_PITCH = WG_CO + 32, B_PITCH = WG_CI + 32, B_ROWS = WG_KP + WG_TAPS;   // 72 rows
-constexpr int A_IMG = WG_KP * A_PITCH, B_IMG = B_ROWS * B_PITCH;
+constexpr int B_ROWS = WG_KP + WG_TAPS;   // 72 rows
+// Row pitches (elements) by MFMA shape.  32x32x16 form: a 32-lane half reads 4 rows x 64 bytes, pitch = 16
+// banks (mod 64).  16x16x32 form: a half reads 8 consecutive rows x 32 bytes, pitch = an odd multiple of
+// 8 banks.  Both conflict-free for ds_read_b64_tr_b16.
+template <bool S16> struct Img {
+    static constexpr int A_PITCH = S16 ? WG_CO + 16 : WG_CO + 32;
+    static constexpr int B_PITCH = S16 ? WG_CI + 16 : WG_CI + 32;
+    static constexpr int A_IMG = WG_KP * A_PITCH, B_IMG = B_ROWS * B_PITCH;
+};
 
 struct WgradParams {
     ac_wgrad_desc d;
@@ -48,10 +55,30 @@ __device__ __forceinline__ bf16x8 frag_t(const unsigned short *img, int colbase,
     return r;
 }
 
-template <bool SPLIT>
+// 16x16x32 form: lane l holds column (l & 15) of a 16-column block and 8 of the step's 32 k (positions);
+// the k of lane group g = l >> 4 are rows 16(g>>1) + 4(g&1) + {0..3, 8..11} of the step — any assignment
+// works as long as both operands use the same one, and this one lets a 32-lane half read 8 consecutive
+// rows (conflict-free at the pitches above).
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag16_t(const unsigned short *img, int colbase, int s2, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int k0 = 32 * s2 + 16 * (g >> 1) + 4 * (g & 1);
+    const unsigned short *a0 = img + (k0 + q) * PITCH + colbase + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 8 * PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <bool SPLIT, bool S16>
 __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
     const ac_wgrad_desc &d = p.d;
+    constexpr int A_PITCH = Img<S16>::A_PITCH, B_PITCH = Img<S16>::B_PITCH;
+    constexpr int A_IMG = Img<S16>::A_IMG, B_IMG = Img<S16>::B_IMG;
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = NPL * (A_IMG + B_IMG);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -110,15 +137,58 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
         }
     };
 
-    f32x16 acc[2][4];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 acc[2][4];     // 32x32x16 form: [32 output channels][tap pair x 32 input channels]
+    f32x4 acs[4][8];      // 16x16x32 form: [16 output channels][tap (2) x 16 input channels (4)]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](const unsigned short *stage) {
+    auto compute16 = [&](const unsigned short *stage) {
+        const unsigned short *ah = stage, *al = stage + A_IMG;
+        const unsigned short *bh = stage + NPL * A_IMG, *bl = bh + B_IMG;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 a_h[4], a_l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a_h[i] = frag16_t<A_PITCH>(ah, wm * 64 + 16 * i, s2, lane);
+                if (SPLIT) a_l[i] = frag16_t<A_PITCH>(al, wm * 64 + 16 * i, s2, lane);
+            }
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int tap = 2 * wn + tp;
+                bf16x8 b_h[4], b_l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    b_h[j] = frag16_t<B_PITCH>(bh + tap * B_PITCH, 16 * j, s2, lane);
+                    if (SPLIT) b_l[j] = frag16_t<B_PITCH>(bl + tap * B_PITCH, 16 * j, s2, lane);
+                }
+                if (SPLIT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acs[i][4 * tp + j] = AC_MFMA16S(a_l[i], b_h[j], acs[i][4 * tp + j]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acs[i][4 * tp + j] = AC_MFMA16S(a_h[i], b_l[j], acs[i][4 * tp + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acs[i][4 * tp + j] = AC_MFMA16S(a_h[i], b_h[j], acs[i][4 * tp + j]);
+            }
+        }
+    };
+    auto compute32 = [&](const unsigned short *stage) {
         const unsigned short *ah = stage, *al = stage + A_IMG;
         const unsigned short *bh = stage + NPL * A_IMG, *bl = bh + B_IMG;
 #pragma unroll
@@ -148,6 +218,10 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
         }
     };
 
+    auto compute = [&](const unsigned short *stage) {
+        if constexpr (S16) compute16(stage);
+        else compute32(stage);
+    };
     unsigned short *S0 = smw, *S1 = smw + STAGE;
     u32x4 ra[2 * NPL], rb[2 * NPL];
     gload_step(s_begin, ra, rb);
@@ -165,6 +239,23 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
 
     // dW[co, t, ci] += acc (fp32 atomics; lanes 0..31 of a register cover 32 consecutive ci)
     float *dw = d.dw;
+    if constexpr (S16) {
+        // 16x16x32 accumulators: register e of lane l = (output channel 4(l>>4) + e, input channel l & 15)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = t0 + 2 * wn + (j >> 2);
+            if (tap >= d.k) continue;
+            const int ci = cit * WG_CI + 16 * (j & 3) + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cot * WG_CO + wm * 64 + 16 * i + 4 * (lane >> 4) + e;
+                    atomicAdd(dw + (int64_t)co * d.ldw + (int64_t)tap * d.Cin + ci, acs[i][j][e]);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int tap = t0 + 2 * wn + (j >> 1);
@@ -180,16 +271,16 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool S16>
 int launch_wgrad(WgradParams &p, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
-    constexpr size_t LDS = (size_t)2 * NPL * (A_IMG + B_IMG) * sizeof(short);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT>,
+    constexpr size_t LDS = (size_t)2 * NPL * (Img<S16>::A_IMG + Img<S16>::B_IMG) * sizeof(short);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT, S16>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (attr != hipSuccess) return -(int)attr - 2000;
     const ac_wgrad_desc &d = p.d;
     dim3 grid(p.co_tiles * p.ci_tiles * p.tap_chunks, (p.steps_total + p.steps_per_split - 1) / p.steps_per_split);
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT>), grid, dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT, S16>), grid, dim3(512), LDS, stream, p);
     AC_CHECK_LAUNCH();
     (void)d;
     return AC_OK;
@@ -219,5 +310,8 @@ extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream)
     p.steps_per_split = (p.steps_total + split - 1) / split;
     const bool sp = d.dy_lo_off != 0 || d.x_lo_off != 0;
     if (sp && (d.dy_lo_off == 0 || d.x_lo_off == 0)) return AC_EINVAL;
-    return sp ? launch_wgrad<true>(p, (hipStream_t)stream) : launch_wgrad<false>(p, (hipStream_t)stream);
+    // variant 2: the 32x32x16 form (A/B measurements); default: v_mfma_f32_16x16x32 (higher sustained clock)
+    if (d.variant == 2)
+        return sp ? launch_wgrad<true, false>(p, (hipStream_t)stream) : launch_wgrad<false, false>(p, (hipStream_t)stream);
+    return sp ? launch_wgrad<true, true>(p, (hipStream_t)stream) : launch_wgrad<false, true>(p, (hipStream_t)stream);
 }

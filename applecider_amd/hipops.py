@@ -236,6 +236,9 @@ def x3_mode() -> bool:
     return _MATH == _lib.MATH_BF16X3
 
 
+_X3_VARIANT = 0   # 0: v_mfma_f32_16x16x32 form (default) ; 2: the 32x32x16 form (A/B measurements, tests)
+
+
 def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w_planes,
                    w_row_stride, w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate) -> bool:
     """Split-bf16 conv through the LDS-resident-window kernel: three passes over (hi, lo) operand
@@ -254,6 +257,7 @@ def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, 
         d.bias, d.accumulate = _p(bias), int(accumulate)
         d.a_lo_off = (al.data_ptr() - ah.data_ptr()) // 2
         d.w_lo_off = (wl.data_ptr() - wh.data_ptr()) // 2
+        d.variant = _X3_VARIANT
         rc = _lib_().ac_conv1d_window_x3(C.byref(d), _stream())
         if rc == 0:
             return True
@@ -470,6 +474,7 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     steps = B * (L // 64)
     d.split_k = max(1, min(steps // 16, -(-512 // tiles)))
     d.dw, d.ldw = _p(dw), k * Cin
+    d.variant = _X3_VARIANT
     d.dy_lo_off = (dy_lo.data_ptr() - dy.data_ptr()) // 2 if dy_lo is not None else 0
     d.x_lo_off = (x_lo.data_ptr() - x.data_ptr()) // 2 if x_lo is not None else 0
     rc = _lib_().ac_conv1d_wgrad_bf16(C.byref(d), _stream())

@@ -367,6 +367,7 @@ typedef struct ac_wgrad_desc {
     float *dw;
     int64_t ldw;
     int64_t dy_lo_off, x_lo_off;
+    int32_t variant;              /* 0: v_mfma_f32_16x16x32 tiles (default); 2: the 32x32x16 form (A/B tests) */
 } ac_wgrad_desc;
 int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *d, ac_stream_t stream);
 

@@ -14,6 +14,7 @@ import bench
 dev = torch.device('cuda')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 H.set_math(sys.argv[2] if len(sys.argv) > 2 else "bf16")
+H._X3_VARIANT = int(os.environ.get("APPLECIDER_X3_VARIANT", "0"))
 torch.manual_seed(0)
 net = AppleCider(dict(bench.FUSION_CFG)).to(dev).train()
 net.branch_streams = False   # one stream: a launch's HIP-event bracket then times that launch alone
