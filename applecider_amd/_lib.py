@@ -70,6 +70,16 @@ class WgradDesc(C.Structure):
                 ("dy_lo_off", C.c_int64), ("x_lo_off", C.c_int64), ("variant", C.c_int32)]
 
 
+class TowerDesc(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in
+                 ("x", "w1", "b1", "lnm_g", "lnm_b", "lng_g", "lng_b", "wm", "bm", "wg", "bg", "ws", "bs", "y", "save",
+                  "dy", "dx", "dw1", "db1", "dlnm_g", "dlnm_b", "dlng_g", "dlng_b", "dwm", "dbm", "dwg", "dbg",
+                  "dws", "dbs")] +
+                [(n, C.c_int64) for n in ("ldx", "ldy", "lddy", "lddx")] +
+                [(n, C.c_int32) for n in ("n_in", "hid", "n_out", "gather", "group_id")] +
+                [("eps", C.c_float), ("cols", C.c_uint8 * 24)])
+
+
 class AdamSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -141,6 +151,8 @@ SIGNATURES = {
     "ac_adam_flat_dev": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _P, _P, _P],
     "ac_step_advance": [_P, _P],
     "ac_sgd_flat": [_P, _P, _P, _I64, _F, _F, _F, _I32, _P],
+    "ac_tower_blocks_fwd": [C.POINTER(TowerDesc), _I32, _I32, _F, _I32, _U64, _P, _P],
+    "ac_tower_blocks_bwd": [C.POINTER(TowerDesc), _I32, _I32, _F, _I32, _U64, _P, _P],
     "ac_sumsq": [_P, _I64, _P, _P],
     "ac_clip_coef": [_P, _F, _P, _P],
 }

@@ -1112,6 +1112,122 @@ class _MoETop2(Function):
         return ds, deo
 
 
+# --------------------------------------------------------------------------- fused tower blocks
+_TOWER_PARAMS = ("w1", "b1", "lnm_g", "lnm_b", "lng_g", "lng_b", "wm", "bm", "wg", "bg", "ws", "bs")
+FUSED_TOWERS = True   # AstroMiNN's towers / experts through ac_tower_blocks_* (tests switch it off to compare)
+
+
+class TowerPlan:
+    """Static description of one grouped launch of ResidualTowerBlocks (ac_tower_blocks_fwd/bwd).
+
+    blocks     list of dicts: n_in, hid, n_out, eps, cols (list of metadata columns or None), y_off (element
+               offset of the block's output inside the output buffer: an int or a function of B), ldy
+    out_shape  B -> shape of the output buffer ([B, width] concatenation, or [E, B, C] stacked experts)
+    extra_off  column offset at which an `extra` [B, w] tensor is copied into a 2-D output (the image
+               tower's features inside the concatenation), or None
+    need_dx    whether dL/dx is wanted (experts: yes; towers on raw metadata: no)
+    group_base first dropout group id (blocks of different launches must not share ids)"""
+
+    def __init__(self, blocks, out_shape, extra_off=None, need_dx=False, group_base=0, p_drop=0.25):
+        if not 1 <= len(blocks) <= 8:
+            raise ValueError("1..8 blocks per grouped launch")
+        self.blocks, self.out_shape, self.extra_off = blocks, out_shape, extra_off
+        self.need_dx, self.group_base, self.p_drop = need_dx, group_base, float(p_drop)
+
+
+def _tower_descs(plan, B, x, ldx, params, out, save, sv_off):
+    arr = (_lib.TowerDesc * len(plan.blocks))()
+    for i, (blk, d) in enumerate(zip(plan.blocks, arr)):
+        pr = params[12 * i:12 * i + 12]
+        d.x, d.ldx = _p(x), ldx
+        for name, t in zip(_TOWER_PARAMS, pr):
+            setattr(d, name, _p(t))
+        d.n_in, d.hid, d.n_out, d.eps = blk["n_in"], blk["hid"], blk["n_out"], blk["eps"]
+        d.group_id = plan.group_base + i
+        cols = blk.get("cols")
+        d.gather = 1 if cols is not None else 0
+        if cols is not None:
+            for j, c in enumerate(cols):
+                d.cols[j] = c
+        d.y, d.ldy = _p(out, _yoff(blk, B)), blk["ldy"]
+        d.save = _p(save, sv_off[i])
+    return arr
+
+
+def _yoff(blk, B):
+    off = blk["y_off"]
+    return off(B) if callable(off) else off
+
+
+class _TowerBlocks(Function):
+    @staticmethod
+    def forward(ctx, x, extra, plan, training, *params):
+        x = _chk(x, "x")
+        B, ldx = x.shape
+        dev = x.device
+        out = torch.empty(*plan.out_shape(B), device=dev, dtype=torch.float32)
+        svw = [b["hid"] + 2 * b["n_out"] + 2 for b in plan.blocks]
+        sv_off = [0]
+        for w in svw:
+            sv_off.append(sv_off[-1] + B * w)
+        save = torch.empty(sv_off[-1], device=dev, dtype=torch.float32)
+        drop = bool(training) and plan.p_drop > 0.0
+        seed = next_seed() if drop else 0
+        arr = _tower_descs(plan, B, x, ldx, params, out, save, sv_off)
+        _lib.check(_lib_().ac_tower_blocks_fwd(arr, len(plan.blocks), B, plan.p_drop, int(drop), seed,
+                                               _p(_STEP_DEV), _stream()), "ac_tower_blocks_fwd")
+        if extra is not None:
+            extra = _chk(extra, "extra")
+            w = extra.shape[1]
+            _lib.check(_lib_().ac_copy2d(_p(extra), w, _p(out, plan.extra_off), out.shape[1], B, w, _stream()),
+                       "ac_copy2d")
+            ctx.extra_w = w
+        ctx.has_extra = extra is not None
+        ctx.plan, ctx.drop, ctx.seed, ctx.sv_off = plan, drop, seed, sv_off
+        ctx.params = params
+        ctx.save_for_backward(x, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _no_f16_backward()
+        x, save = ctx.saved_tensors
+        plan, params = ctx.plan, ctx.params
+        B, ldx = x.shape
+        dev = x.device
+        dout = _chk(dout, "dout")
+        arr = _tower_descs(plan, B, x, ldx, params, dout, save, ctx.sv_off)   # y slot unused by backward
+        dx = torch.zeros_like(x) if (plan.need_dx and ctx.needs_input_grad[0]) else None
+        grads, written = [], []
+        for i, (blk, d) in enumerate(zip(plan.blocks, arr)):
+            d.dy, d.lddy = _p(dout, _yoff(blk, B)), blk["ldy"]
+            d.dx, d.lddx = _p(dx), ldx
+            for name, t in zip(_TOWER_PARAMS, params[12 * i:12 * i + 12]):
+                if t is None:
+                    grads.append(None)
+                    continue
+                sink = _sink(t)
+                g = sink if sink is not None else torch.zeros_like(t)
+                setattr(d, "d" + name, _p(g))
+                grads.append(None if sink is not None else g)
+                if sink is not None:
+                    written.append(t)
+        _lib.check(_lib_().ac_tower_blocks_bwd(arr, len(plan.blocks), B, plan.p_drop, int(ctx.drop), ctx.seed,
+                                               _p(_STEP_DEV), _stream()), "ac_tower_blocks_bwd")
+        for t in written:
+            _grad_written(t)
+        dextra = None
+        if ctx.has_extra and ctx.needs_input_grad[1]:
+            dextra = dout[:, plan.extra_off:plan.extra_off + ctx.extra_w].contiguous()
+        return (dx, dextra, None, None, *grads)
+
+
+def tower_blocks(x, extra, plan: TowerPlan, training: bool, params):
+    """Grouped fused ResidualTowerBlocks: x [B, ldx] -> the plan's output buffer.  `params` = 12 tensors per
+    block in _TOWER_PARAMS order (ws, bs None for an identity skip)."""
+    return _TowerBlocks.apply(x, extra, plan, training, *params)
+
+
 def moe_top2(scores, expert_out):
     """scores [B,E], expert_out [E,B,C] -> (out [B,C], sel [B,2])."""
     return _MoETop2.apply(scores, expert_out)

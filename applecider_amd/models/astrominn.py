@@ -149,8 +149,68 @@ class AstroMiNN(nn.Module):
             return H.cross_entropy_index(logits, target)
         return H.cross_entropy_soft(logits, target)
 
+    # ---- fused path: the 8 towers (+ the image features' slot) and the 4 experts as two grouped launches
+    _TOWER_ORDER = (("nst1_tower", "nst1"), ("nst2_tower", "nst2"), ("spatial_tower", "spatial"), ("psf_tower", "psf"),
+                    ("mag_tower", "mag"), ("coord_tower", "coord"), ("mega_tower", "mega"), (None, "image"),
+                    ("lc_tower", "lc"))   # concatenation order of astrominn.py:264-267
+
+    @staticmethod
+    def _block_params(blk):
+        s, lm, wm = blk.start_path[0], blk.main_path[0], blk.main_path[2]
+        lg, wg = blk.activation[0], blk.activation[2]
+        sk = blk.skip_path if isinstance(blk.skip_path, Linear) else None
+        return [s.weight, s.bias, lm.weight, lm.bias, lg.weight, lg.bias, wm.weight, wm.bias, wg.weight, wg.bias,
+                sk.weight if sk is not None else None, sk.bias if sk is not None else None]
+
+    @staticmethod
+    def _block_fits(blk):
+        s = blk.start_path[0]
+        return s.in_features <= 288 and s.out_features <= 128 and blk.main_path[2].out_features <= 32
+
+    def _plans(self):
+        """(tower plan, tower params, expert plan, expert params) or None when a block exceeds the fused
+        kernel's limits (the per-op path below handles any size)."""
+        if getattr(self, "_fused_plans", None) is not None:
+            return self._fused_plans or None
+        towers = [getattr(self, n) for n, _ in self._TOWER_ORDER if n is not None]
+        experts = list(self.fusion_experts)
+        ok = (all(self._block_fits(b) for b in towers + experts) and len(experts) <= 8 and
+              all(len(_COLS[k]) <= 24 for _, k in self._TOWER_ORDER if k != "image"))
+        if not ok:
+            self._fused_plans = False
+            return None
+        blocks, off, img_off = [], 0, None
+        for name, key in self._TOWER_ORDER:
+            if name is None:
+                img_off, off = off, off + self.towers_outdims
+                continue
+            b = getattr(self, name)
+            n_out = b.main_path[2].out_features
+            blocks.append({"n_in": len(_COLS[key]), "hid": b.start_path[0].out_features, "n_out": n_out,
+                           "eps": b.main_path[0].eps, "cols": _COLS[key], "y_off": off, "ldy": None})
+            off += n_out
+        width = off
+        for blk in blocks:
+            blk["ldy"] = width
+        tplan = H.TowerPlan(blocks, lambda B: (B, width), extra_off=img_off, need_dx=False, group_base=0)
+        tparams = [t for b in towers for t in self._block_params(b)]
+        E, C = len(experts), experts[0].main_path[2].out_features
+        eblocks = [{"n_in": width, "hid": e.start_path[0].out_features, "n_out": C, "eps": e.main_path[0].eps,
+                    "cols": None, "y_off": (lambda B, i=i: i * B * C), "ldy": C} for i, e in enumerate(experts)]
+        eplan = H.TowerPlan(eblocks, lambda B: (E, B, C), need_dx=True, group_base=8)
+        eparams = [t for e in experts for t in self._block_params(e)]
+        self._fused_plans = (tplan, tparams, eplan, eparams)
+        return self._fused_plans
+
     def features(self, metadata, image):
         md = metadata
+        plans = self._plans() if H.FUSED_TOWERS else None
+        if plans is not None:
+            if image is not None:
+                img = self.image_tower(image)
+            else:
+                img = torch.zeros(md.shape[0], self.towers_outdims, device=md.device, dtype=torch.float32)
+            return H.tower_blocks(md, img, plans[0], self.training, plans[1])
         t = lambda tower, key: tower(H.gather_cols(md, getattr(self, f"_cols_{key}")))
         nsta = t(self.nst1_tower, "nst1")
         nstb = t(self.nst2_tower, "nst2")
@@ -172,7 +232,11 @@ class AstroMiNN(nn.Module):
         r = self.fusion_router
         h = r[2](r[0](all_feats, act="tanh"))
         fusion_weights = r[3](h, act="sigmoid")
-        expert_out = H.stack0([expert(all_feats) for expert in self.fusion_experts])
+        plans = self._plans() if H.FUSED_TOWERS else None
+        if plans is not None:
+            expert_out = H.tower_blocks(all_feats, None, plans[2], self.training, plans[3])
+        else:
+            expert_out = H.stack0([expert(all_feats) for expert in self.fusion_experts])
         moe_output, _sel = H.moe_top2(fusion_weights, expert_out)
         if self.config["model"]["AstroMiNN"]["use_probabilities"]:
             moe_output = H.softmax_rows(moe_output)

@@ -393,6 +393,43 @@ int ac_moe_top2_fwd(const float *scores, const float *expert_out, float *out, in
 int ac_moe_top2_bwd(const float *dout, const float *scores, const float *expert_out,
                     const int32_t *sel, float *dscores, float *dexpert_out, int32_t B,
                     int32_t E, int32_t C, ac_stream_t stream);
+/* Grouped, fully fused ResidualTowerBlock (astrominn.py:44-64): up to 8 blocks per launch — the eight
+ * metadata towers (astrominn.py:94-113 on the column subsets of :249-261) or the four fusion experts
+ * (:129-131) — forward and backward.  Per block and sample:
+ *   h    = GELU(W1 x + b1)                    x = metadata[:, cols] when gather != 0, else x[:, 0..n_in)
+ *   xhat = (h - mean(h)) * rsqrt(var(h) + eps)            (both LayerNorms normalise the same h)
+ *   y    = (Wm drop(xhat*lnm_g + lnm_b) + bm) * sigmoid(Wg drop(xhat*lng_g + lng_b) + bg) + skip(x)
+ *   skip = Ws x + bs, or x when ws == NULL (n_in == n_out)
+ * y is written at y + sample*ldy (the caller points it into the concatenated feature buffer / the
+ * stacked expert outputs).  save [B, hid + 2*n_out + 2] keeps (pre-GELU hidden | main | gate | mean, rstd)
+ * for the backward call, which recomputes the rest, adds every parameter gradient to d* with fp32
+ * atomics (buffers zeroed or pre-filled by the caller) and, when dx != NULL, adds dL/dx into
+ * dx[sample*lddx + column] (atomics too: the four experts share one input).
+ * Dropout (p_drop, training != 0): keep decisions from (seed', group_id, path, sample, hidden index) with
+ * seed' as in ac_dropout; forward and backward must be given the same seed / step counter value.
+ * Limits: n_in <= 288 (<= 24 with gather), hid <= 128, n_out <= 32, n <= 8.  Exact fp32 FMA arithmetic. */
+typedef struct ac_tower_desc {
+    const float *x;
+    const float *w1, *b1;                                /* [hid, n_in], [hid] */
+    const float *lnm_g, *lnm_b, *lng_g, *lng_b;          /* LayerNorm affine of the main / gate path, [hid] */
+    const float *wm, *bm, *wg, *bg;                      /* [n_out, hid], [n_out] */
+    const float *ws, *bs;                                /* skip Linear [n_out, n_in], [n_out]; NULL = identity */
+    float *y;
+    float *save;
+    const float *dy;                                     /* backward only from here */
+    float *dx;
+    float *dw1, *db1, *dlnm_g, *dlnm_b, *dlng_g, *dlng_b, *dwm, *dbm, *dwg, *dbg, *dws, *dbs;
+    int64_t ldx, ldy, lddy, lddx;
+    int32_t n_in, hid, n_out;
+    int32_t gather;                                      /* 1: x columns are cols[0..n_in) */
+    int32_t group_id;                                    /* distinguishes the blocks' dropout streams */
+    float eps;
+    uint8_t cols[24];
+} ac_tower_desc;
+int ac_tower_blocks_fwd(const ac_tower_desc *groups_host, int32_t n, int32_t B, float p_drop, int32_t training,
+                        uint64_t seed, const uint64_t *step, ac_stream_t stream);
+int ac_tower_blocks_bwd(const ac_tower_desc *groups_host, int32_t n, int32_t B, float p_drop, int32_t training,
+                        uint64_t seed, const uint64_t *step, ac_stream_t stream);
 /* y = x / ||x||_2 per row. */
 int ac_l2norm_fwd(const float *x, float *y, float *norm, int64_t rows, int32_t C,
                   ac_stream_t stream);
