@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libapplecider_hip.so")
+LIB_PATH = os.environ.get("APPLECIDER_HIP_LIB") or os.path.join(_HERE, "csrc", "libapplecider_hip.so")   # override: another build of the same ABI
 # the same sources built with IEEE fp16 as the 16-bit operand format (csrc/Makefile, ac_common.h):
 # the inference library behind hipops.set_math("f16") (BASELINE configs[4])
 LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libapplecider_hip_f16.so")
