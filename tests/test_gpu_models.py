@@ -248,8 +248,20 @@ def test_baselinecls_dropout_training(dev):
     assert torch.equal(a, c)
 
 
-def test_applecider_fusion_vs_oracle(dev):
-    """Full 4-modality forward/backward (config 3 shape at B = 4) against the CPU oracle."""
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_applecider_fusion_vs_oracle(dev, mode):
+    """Full 4-modality forward/backward (config 3 shape at B = 4) against the CPU oracle, in both qualified
+    arithmetic modes: the benchmarked one (split bf16) is held to the same bounds as the exact one, logits,
+    loss and all ~450 gradients."""
+    from applecider_amd import hipops as Hm
+    Hm.set_math(mode)
+    try:
+        _fusion_vs_oracle(dev)
+    finally:
+        Hm.set_math("f32")
+
+
+def _fusion_vs_oracle(dev):
     from applecider_amd.models.applecider import AppleCider
     from applecider_amd.synthetic import make_batch
     from oracle import functional as O
