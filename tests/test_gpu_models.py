@@ -256,12 +256,12 @@ def test_applecider_fusion_vs_oracle(dev, mode):
     from applecider_amd import hipops as Hm
     Hm.set_math(mode)
     try:
-        _fusion_vs_oracle(dev)
+        _fusion_vs_oracle(dev, mode)
     finally:
         Hm.set_math("f32")
 
 
-def _fusion_vs_oracle(dev):
+def _fusion_vs_oracle(dev, mode="f32"):
     from applecider_amd.models.applecider import AppleCider
     from applecider_amd.synthetic import make_batch
     from oracle import functional as O
@@ -290,9 +290,24 @@ def _fusion_vs_oracle(dev):
         m.optimizer.zero_grad()
         loss.backward()
         gr = grads_by_ref_name(m)
-        checked = 0
+        checked, loose = 0, []
         for k, ref_t in osd.items():
             if ref_t.grad is None or k not in gr:
+                continue
+            if mode == "bf16x3" and "spectra_encoder.all_stages" not in k:
+                # Split-bf16 products differ from fp32 by ~2e-5 instead of ~5e-7, so at B = 4 a few ReLU
+                # gates of the encoder feed-forward / the image head sit on the other side of zero than in the
+                # CPU run (the same discontinuity argument as for the max-pool below, one flipped gate moves
+                # one row of dW by O(1/B)): every tensor keeps the aggregate bound, and all but a few the
+                # tight one.
+                a, r = gr[k].detach().cpu().double().flatten(), ref_t.grad.double().flatten()
+                cos = float((a @ r) / (a.norm() * r.norm() + 1e-300))
+                assert cos >= 0.9995, f"{fusion} grad {k}: cosine {cos}"
+                assert_close(gr[k], ref_t.grad, 3e-2, f"{fusion} grad {k}")
+                e = float((a - r).abs().max() / r.abs().max().clamp_min(1e-30))
+                if e > 5e-3:
+                    loose.append((k, e))
+                checked += 1
                 continue
             if "spectra_encoder.all_stages" in k:
                 # Upstream of MaxPool1d the gradient is discontinuous: a single window whose two
@@ -303,11 +318,15 @@ def _fusion_vs_oracle(dev):
                 a, r = gr[k].detach().cpu().double().flatten(), ref_t.grad.double().flatten()
                 cos = float((a @ r) / (a.norm() * r.norm() + 1e-300))
                 assert cos >= 0.9995, f"{fusion} grad {k}: cosine {cos}"
-                assert_close(gr[k], ref_t.grad, 3e-2, f"{fusion} grad {k}")
+                # (bf16x3: ~40x more windows inside the rounding band than in fp32 mode, each flip moves its
+                # tensors by O(1/(B*L)) at B = 4; the direction stays pinned by the cosine)
+                assert_close(gr[k], ref_t.grad, 8e-2 if mode == "bf16x3" else 3e-2, f"{fusion} grad {k}")
             else:
                 assert_close(gr[k], ref_t.grad, 5e-3, f"{fusion} grad {k}")
             checked += 1
         assert checked > 400
+        print(f"[fusion vs oracle] {mode} {fusion}: {checked} gradients, beyond 5e-3: {loose}")
+        assert len(loose) <= 0.03 * checked, loose
 
 
 def test_applecider_train_step_bf16_runs(dev):
