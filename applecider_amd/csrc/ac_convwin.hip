@@ -479,19 +479,23 @@ int launch_ks2(ConvWinParams &p, hipStream_t stream) {
 // stay in registers.  TC is chosen by the host so that the chunk fits the 160 KB LDS (k = 251 at
 // 64 channels: two chunks of 129 + 122 taps).
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, bool S16>
-__global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWinParams p, int TC) {
-    constexpr int NT = WM * WN * 64, BM = WM * 64, BN = WN * 64, CC = 64;
-    constexpr int BCH = BN * 8 / NT;          // weight chunks per thread per plane per K tile
+// GR = 2 (N <= 64: the tile has only WM x 1 waves): a second group of waves works on the same output tile
+// and the same window but on the ODD taps of the chunk (group 0: even taps), each group with its own
+// weight stages; the groups add their accumulators through LDS at the end.  Two waves per SIMD instead
+// of one, which the 4-wave tile lacked (one wave cannot cover its own LDS latency).
+template <int WM, int WN, bool S16, int GR>
+__global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWinParams p, int TC) {
+    constexpr int GT = WM * WN * 64, NT = GR * GT, BM = WM * 64, BN = WN * 64, CC = 64;
+    constexpr int BCH = BN * 8 / GT;          // weight chunks per thread per plane per K tile (per group)
     constexpr int WT = BN * 64;               // one weight plane tile (elements)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *win_h = reinterpret_cast<unsigned short *>(smem);
     const ac_convwin_desc &d = p.d;
     const int Wrows = (d.L < BM ? (BM / d.L) * (d.L + TC - 1) : BM + TC - 1);
     unsigned short *win_l = win_h + Wrows * CC;
-    unsigned short *bst = win_l + Wrows * CC;  // 2 stages x (hi tile | lo tile)
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int grp = (t >> 6) / (WM * WN), wave = (t >> 6) % (WM * WN), tg = t % GT;
+    unsigned short *bst = win_l + Wrows * CC + grp * 4 * WT;  // per group: 2 stages x (hi tile | lo tile)
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
@@ -512,9 +516,9 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     int64_t wbase[BCH];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-        int n = tn * BN + (t >> 3) + (NT / 8) * i;
+        int n = tn * BN + (tg >> 3) + (GT / 8) * i;
         n = n < d.N ? n : d.N - 1;
-        wbase[i] = (int64_t)n * d.w_row_stride + 8 * (t & 7);
+        wbase[i] = (int64_t)n * d.w_row_stride + 8 * (tg & 7);
     }
 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -547,8 +551,13 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                     *(u32x4 *)(win_l + win_off<64>(rr, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
                 }
             }
+            // K tile kt of this group = tap GR * kt + grp of the chunk; a tile past the chunk's last tap loads
+            // the last tap (in bounds) and is zeroed when stored
+            const int ntile = (tc + GR - 1) / GR;
             auto wload = [&](int kt, u32x4 (&v)[2 * BCH]) {
-                const int tap = t0 + kt;
+                int tl = GR * kt + grp;
+                tl = tl < tc ? tl : tc - 1;
+                const int tap = t0 + tl;
                 const int64_t ko = (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + cch * CC;
 #pragma unroll
                 for (int i = 0; i < BCH; ++i) {
@@ -556,11 +565,15 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                     v[BCH + i] = ac_gload<u32x4>(wptr + wbase[i] + ko + d.w_lo_off);
                 }
             };
-            auto wstore = [&](unsigned short *stage, const u32x4 (&v)[2 * BCH]) {
-                const int c = t & 7;
+            auto wstore = [&](unsigned short *stage, int kt, u32x4 (&v)[2 * BCH]) {
+                const int c = tg & 7;
+                if (GR > 1 && GR * kt + grp >= tc) {
+#pragma unroll
+                    for (int i = 0; i < 2 * BCH; ++i) v[i] = u32x4{0u, 0u, 0u, 0u};
+                }
 #pragma unroll
                 for (int i = 0; i < BCH; ++i) {
-                    const int r = (t >> 3) + (NT / 8) * i;
+                    const int r = (tg >> 3) + (GT / 8) * i;
                     const int off = r * 64 + ((c ^ ((r >> 1) & 7)) << 3);
                     *(u32x4 *)(stage + off) = v[i];
                     *(u32x4 *)(stage + WT + off) = v[BCH + i];
@@ -677,32 +690,73 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
                 else compute32(kt, bt);
             };
             unsigned short *S0 = bst, *S1 = bst + 2 * WT;
-            const int last = tc - 1;
+            const int last = ntile - 1;
+            // window row offset of this group's K tile kt (clamped: a padded tile multiplies zero weights
+            // with rows that must still be finite window data)
+            auto tapoff = [&](int kt) { const int o = GR * kt + grp; return o < tc ? o : tc - 1; };
             u32x4 rb0[2 * BCH], rb1[2 * BCH];
             wload(0, rb0);
-            wstore(S0, rb0);
+            wstore(S0, 0, rb0);
             __syncthreads();  // window + first weight tile visible
             wload(1 < last ? 1 : last, rb0);
-            for (int kt = 0; kt < tc; kt += 2) {
+            for (int kt = 0; kt < ntile; kt += 2) {
                 wload(kt + 2 < last ? kt + 2 : last, rb1);
                 __builtin_amdgcn_sched_barrier(0);
-                compute(kt, S0);
-                wstore(S1, rb0);
+                compute(tapoff(kt), S0);
+                wstore(S1, kt + 1, rb0);
                 __syncthreads();
-                if (kt + 1 >= tc) break;
+                if (kt + 1 >= ntile) break;
                 wload(kt + 3 < last ? kt + 3 : last, rb0);
                 __builtin_amdgcn_sched_barrier(0);
-                compute(kt + 1, S1);
-                wstore(S0, rb1);
+                compute(tapoff(kt + 1), S1);
+                wstore(S0, kt + 2, rb1);
                 __syncthreads();
             }
         }
     }
     __syncthreads();
+    if constexpr (GR == 2) {   // group 1 hands its accumulators to group 0 through the (idle) window
+        float *xch = smem + wave * 4096;
+        if (grp == 1) {
+            if constexpr (S16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xch[((i * 4 + j) * 4 + e) * 64 + lane] = acs[i][j][e];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) xch[((i * 2 + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        if constexpr (S16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acs[i][j][e] += xch[((i * 4 + j) * 4 + e) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * 2 + j) * 16 + e) * 64 + lane];
+        }
+        // (a wave parks only its own 8 KB below and reads its own 16 KB above: no barrier needed)
+    }
 
     // ---- epilogue (fp32 output only): out[R0 + m, n] (+)= acc (+ bias), 16-byte stores through LDS
     float *cb = d.c + (int64_t)R0 * d.ldc;
-    float *wbuf = smem + wave * 2048;
+    float *wbuf = smem + wave * (GR == 2 ? 4096 : 2048);   // GR = 2: inside the wave's own exchange region
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = tn * BN + wn * 64 + c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -739,32 +793,33 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_x3_kernel(ConvWi
     }
 }
 
-template <int WM, int WN, bool S16 = true>
+template <int WM, int WN, bool S16 = true, int GR = 1>
 int launch_x3(ConvWinParams &p, hipStream_t stream) {
-    if (S16 && p.d.variant == 2) return launch_x3<WM, WN, false>(p, stream);   // variant 2: the 32x32x16 form
-    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
+    if (S16 && p.d.variant == 2) return launch_x3<WM, WN, false, 1>(p, stream);   // variant 2: the 32x32x16 form
+    if (GR == 2 && p.d.variant == 3) return launch_x3<WM, WN, S16, 1>(p, stream);    // variant 3: one wave group
+    constexpr int BM = WM * 64, BN = WN * 64, NT = GR * WM * WN * 64;
     const ac_convwin_desc &d = p.d;
-    const size_t stages = (size_t)2 * 2 * BN * 64 * sizeof(short);
+    const size_t stages = (size_t)GR * 2 * 2 * BN * 64 * sizeof(short);
     const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
     const int spt = d.L < BM ? BM / d.L : 1, Ls = d.L < BM ? d.L : BM;
     int TC = rows_budget / spt - Ls + 1;
     if (TC < 1) return AC_EINVAL;
     if (TC > d.k) TC = d.k;
     const size_t lds = (size_t)spt * (Ls + TC - 1) * 64 * 2 * sizeof(short) + stages;
-    if (lds < (size_t)WM * WN * 8192) return AC_EINVAL;   // the epilogue parks 8 KB per wave
+    if (lds < (size_t)WM * WN * (GR == 2 ? 16384 : 8192)) return AC_EINVAL;   // epilogue: 8 KB per wave (group exchange: 16)
     p.tiles_l = d.L / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.cchunks = 8;
     p.vec_epi = 1;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3_kernel<WM, WN, S16>,
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3_kernel<WM, WN, S16, GR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
     const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
-    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
+    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16, GR>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -809,8 +864,11 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
         return AC_EALIGN;
     hipStream_t stream = (hipStream_t)stream_;
     const bool wide = d.N > 64;
-    if (d.L % 256 == 0 || short_seq) return wide ? launch_x3<4, 2>(p, stream) : launch_x3<4, 1>(p, stream);
-    return wide ? launch_x3<2, 2>(p, stream) : launch_x3<2, 1>(p, stream);
+    // N <= 64: one column of waves only -> a second wave group on the odd taps (needs a few taps to share)
+    const bool two = !wide && d.k >= 4;
+    if (d.L % 256 == 0 || short_seq)
+        return wide ? launch_x3<4, 2>(p, stream) : (two ? launch_x3<4, 1, true, 2>(p, stream) : launch_x3<4, 1>(p, stream));
+    return wide ? launch_x3<2, 2>(p, stream) : (two ? launch_x3<2, 1, true, 2>(p, stream) : launch_x3<2, 1>(p, stream));
 }
 
 extern "C" int ac_conv1d_window_bf16(const ac_convwin_desc *dp, ac_stream_t stream_) {
