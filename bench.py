@@ -331,6 +331,9 @@ def main():
                     help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command "
                          "instead of starting it (launcher plumbing test, no GPU needed)")
     args = ap.parse_args()
+    if os.environ.get("APPLECIDER_TRACE_STACKS"):   # development: where is the host blocked?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["APPLECIDER_TRACE_STACKS"]), repeat=True)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher before anything touches the GPU
@@ -411,8 +414,11 @@ def main():
     barrier()
     timer.enabled = args.events_in_timed_region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         loss = step()
+        if os.environ.get("APPLECIDER_TRACE_STEPS"):   # development: host-side time per step (adds a sync)
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] step {i}: {time.perf_counter() - t0:.3f} s since start", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
