@@ -25,7 +25,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_TAPS = 8, WG_KP = 64, WG_CO = 128, WG_CI = 64;
-constexpr int B_ROWS = WG_KP + WG_TAPS;   // 72 rows
+// window rows: 64 positions + 8 taps of one sample; short sequences (L = 16 / 32: SpectraNet stages 4-5 have
+// L = 64 / 16) put 64 / L whole samples in a K step, each with its own L + 8 rows -> at most 4 x 24 = 96
+constexpr int B_ROWS = 96;
 // Row pitches (elements) by MFMA shape.  32x32x16 form: a 32-lane half reads 4 rows x 64 bytes, pitch = 16
 // banks (mod 64).  16x16x32 form: a half reads 8 consecutive rows x 32 bytes, pitch = an odd multiple of
 // 8 banks.  Both conflict-free for ds_read_b64_tr_b16.
@@ -59,10 +61,14 @@ __device__ __forceinline__ bf16x8 frag_t(const unsigned short *img, int colbase,
 // the k of lane group g = l >> 4 are rows 16(g>>1) + 4(g&1) + {0..3, 8..11} of the step — any assignment
 // works as long as both operands use the same one, and this one lets a 32-lane half read 8 consecutive
 // rows (conflict-free at the pitches above).
-template <int PITCH>
-__device__ __forceinline__ bf16x8 frag16_t(const unsigned short *img, int colbase, int s2, int lane) {
+// seg_rows > 0: the image holds 64 / Ls segments of seg_rows rows (one per sample of a short-sequence
+// step); the lane's 8 positions lie inside one aligned 16-block, hence inside one segment.
+// krow >= 0: the image row of the lane group's first position, precomputed by the caller (short sequences).
+template <int PITCH, bool SEG = false>
+__device__ __forceinline__ bf16x8 frag16_t(const unsigned short *img, int colbase, int s2, int lane, int krow = 0) {
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    const int k0 = 32 * s2 + 16 * (g >> 1) + 4 * (g & 1);
+    int k0 = 32 * s2 + 16 * (g >> 1) + 4 * (g & 1);
+    if constexpr (SEG) k0 = krow;
     const unsigned short *a0 = img + (k0 + q) * PITCH + colbase + 4 * pp;
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
@@ -73,7 +79,9 @@ __device__ __forceinline__ bf16x8 frag16_t(const unsigned short *img, int colbas
     return r;
 }
 
-template <bool SPLIT, bool S16>
+// SHORT: L = 16 / 32 (64 / L whole samples per K step); a separate instantiation so that the long-sequence
+// kernel keeps its compile-time addressing (as one runtime-switched kernel it lost 18 %).
+template <bool SPLIT, bool S16, bool SHORT>
 __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
     const ac_wgrad_desc &d = p.d;
@@ -109,27 +117,51 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     // loader roles: dy tile 64 rows x 16 chunks = 1024 chunks (2 per thread); window 72 rows x 8 chunks
     const int ar = t >> 4, ac = t & 15;            // + 32 rows for the second chunk
     const int br = t >> 3, bc = t & 7;             // rows 0..63 ; second chunk: rows 64..71 (t < 64)
-    const int steps_per_seq = d.L / WG_KP;
+    constexpr bool shortL = SHORT;                       // 64 / L whole samples per K step (S16 form only)
+    const int steps_per_seq = shortL ? 1 : d.L / WG_KP;
+    const int lsh = shortL ? 31 - __builtin_clz(d.L) : 6;  // log2 of the positions per sample in a step
+    const int seg = shortL ? d.L + WG_TAPS : 0;           // window rows per sample (short sequences)
+    const int nbrow = shortL ? (WG_KP >> lsh) * seg : WG_KP + WG_TAPS;
 
     auto gload_step = [&](int step, u32x4 (&ra)[2 * NPL], u32x4 (&rb)[2 * NPL]) {
-        const int b = step / steps_per_seq, l0 = (step - b * steps_per_seq) * WG_KP;
-        const unsigned short *ap = dy + (int64_t)b * d.dy_batch_stride +
-                                   (int64_t)(d.dy_row_base + l0 + ar) * d.dy_row_stride + d.dy_col_off +
-                                   cot * WG_CO + ac * 8;
+        int b, l0;
+        int64_t ao0, ao1;
+        if constexpr (shortL) {
+            b = step << (6 - lsh);
+            l0 = 0;
+            // dy tile row r (position r of the step) -> (sample b + (r >> lsh), position r & (L - 1))
+            const int r0 = ar, r1 = ar + 32;
+            ao0 = (int64_t)(r0 >> lsh) * d.dy_batch_stride + (int64_t)(d.dy_row_base + (r0 & ((1 << lsh) - 1))) * d.dy_row_stride;
+            ao1 = (int64_t)(r1 >> lsh) * d.dy_batch_stride + (int64_t)(d.dy_row_base + (r1 & ((1 << lsh) - 1))) * d.dy_row_stride;
+        } else {
+            b = step / steps_per_seq;
+            l0 = (step - b * steps_per_seq) * WG_KP;
+            ao0 = (int64_t)(d.dy_row_base + l0 + ar) * d.dy_row_stride;
+            ao1 = ao0 + 32 * d.dy_row_stride;
+        }
+        const unsigned short *ap = dy + (int64_t)b * d.dy_batch_stride + d.dy_col_off + cot * WG_CO + ac * 8;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            ra[2 * pl] = ac_gload<u32x4>(ap + pl * d.dy_lo_off);
-            ra[2 * pl + 1] = ac_gload<u32x4>(ap + pl * d.dy_lo_off + 32 * d.dy_row_stride);
+            ra[2 * pl] = ac_gload<u32x4>(ap + pl * d.dy_lo_off + ao0);
+            ra[2 * pl + 1] = ac_gload<u32x4>(ap + pl * d.dy_lo_off + ao1);
         }
-        int row0 = d.x_row_base + l0 + t0 + br;
-        int row1 = d.x_row_base + l0 + t0 + 64 + ((t >> 3) & 7);   // rows 64..71 (stored by threads 0..63 only)
+        // window rows: image row w -> (sample w / seg, input row w % seg) for short sequences
+        int w0 = br, w1 = 64 + (t >> 3);          // second pass: rows 64.. (up to 95: all 256 threads)
+        w1 = w1 < nbrow ? w1 : nbrow - 1;
+        int s0 = 0, s1 = 0;
+        if constexpr (shortL) {
+            s0 = w0 / seg; w0 -= s0 * seg;
+            s1 = w1 / seg; w1 -= s1 * seg;
+        }
+        int row0 = d.x_row_base + l0 + t0 + w0;
+        int row1 = d.x_row_base + l0 + t0 + w1;
         row0 = row0 < d.x_rows ? row0 : d.x_rows - 1;
         row1 = row1 < d.x_rows ? row1 : d.x_rows - 1;
         const unsigned short *bp = x + (int64_t)b * d.x_batch_stride + cit * WG_CI + bc * 8;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            rb[2 * pl] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)row0 * d.x_row_stride);
-            rb[2 * pl + 1] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)row1 * d.x_row_stride);
+            rb[2 * pl] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)s0 * d.x_batch_stride + (int64_t)row0 * d.x_row_stride);
+            rb[2 * pl + 1] = ac_gload<u32x4>(bp + pl * d.x_lo_off + (int64_t)s1 * d.x_batch_stride + (int64_t)row1 * d.x_row_stride);
         }
     };
     auto lds_store = [&](unsigned short *stage, const u32x4 (&ra)[2 * NPL], const u32x4 (&rb)[2 * NPL]) {
@@ -139,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
             *(u32x4 *)(ai + ar * A_PITCH + ac * 8) = ra[2 * pl];
             *(u32x4 *)(ai + (ar + 32) * A_PITCH + ac * 8) = ra[2 * pl + 1];
             *(u32x4 *)(bi + br * B_PITCH + bc * 8) = rb[2 * pl];
-            if (t < 64) *(u32x4 *)(bi + (64 + (t >> 3)) * B_PITCH + bc * 8) = rb[2 * pl + 1];
+            if (64 + (t >> 3) < nbrow) *(u32x4 *)(bi + (64 + (t >> 3)) * B_PITCH + bc * 8) = rb[2 * pl + 1];
         }
     };
 
@@ -157,6 +189,14 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // short sequences: window row of this lane group's first position in step half s2 (the group's 8
+    // positions lie inside one aligned 16-block, i.e. inside one sample's segment of the window image)
+    int krow[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int k0 = 32 * s2 + 16 * ((lane >> 4) >> 1) + 4 * ((lane >> 4) & 1);
+        krow[s2] = (k0 >> lsh) * seg + (k0 & ((1 << lsh) - 1));
+    }
     auto compute16 = [&](const unsigned short *stage) {
         const unsigned short *ah = stage, *al = stage + A_IMG;
         const unsigned short *bh = stage + NPL * A_IMG, *bl = bh + B_IMG;
@@ -174,8 +214,8 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
                 bf16x8 b_h[4], b_l[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    b_h[j] = frag16_t<B_PITCH>(bh + tap * B_PITCH, 16 * j, s2, lane);
-                    if (SPLIT) b_l[j] = frag16_t<B_PITCH>(bl + tap * B_PITCH, 16 * j, s2, lane);
+                    b_h[j] = frag16_t<B_PITCH, SHORT>(bh + tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
+                    if (SPLIT) b_l[j] = frag16_t<B_PITCH, SHORT>(bl + tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
                 }
                 if (SPLIT) {
 #pragma unroll
@@ -277,16 +317,16 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     }
 }
 
-template <bool SPLIT, bool S16>
+template <bool SPLIT, bool S16, bool SHORT = false>
 int launch_wgrad(WgradParams &p, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr size_t LDS = (size_t)2 * NPL * (Img<S16>::A_IMG + Img<S16>::B_IMG) * sizeof(short);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT, S16>,
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT, S16, SHORT>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (attr != hipSuccess) return -(int)attr - 2000;
     const ac_wgrad_desc &d = p.d;
     dim3 grid(p.co_tiles * p.ci_tiles * p.tap_chunks * ((p.steps_total + p.steps_per_split - 1) / p.steps_per_split));
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT, S16>), grid, dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT, S16, SHORT>), grid, dim3(512), LDS, stream, p);
     AC_CHECK_LAUNCH();
     (void)d;
     return AC_OK;
@@ -301,7 +341,8 @@ extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream)
     const ac_wgrad_desc &d = p.d;
     if (!d.dy || !d.x || !d.dw || d.B <= 0 || d.L <= 0 || d.k <= 0 || d.Cout <= 0 || d.Cin <= 0) return AC_EINVAL;
     // shapes outside the tile grid go back to the caller's generic TN product
-    if ((d.L % WG_KP) || (d.Cout % WG_CO) || (d.Cin % WG_CI)) return AC_EINVAL;
+    const bool short_seq = d.L < WG_KP && (d.L == 16 || d.L == 32) && ((int64_t)d.B * d.L) % WG_KP == 0 && d.variant != 2;
+    if (((d.L % WG_KP) && !short_seq) || (d.Cout % WG_CO) || (d.Cin % WG_CI)) return AC_EINVAL;
     if (!ac_aligned16(d.dy) || !ac_aligned16(d.x) || (d.dy_row_stride % 8) || (d.dy_batch_stride % 8) ||
         (d.dy_col_off % 8) || (d.x_row_stride % 8) || (d.x_batch_stride % 8) || (d.dy_lo_off % 8) ||
         (d.x_lo_off % 8))
@@ -310,7 +351,7 @@ extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream)
     p.co_tiles = d.Cout / WG_CO;
     p.ci_tiles = d.Cin / WG_CI;
     p.tap_chunks = (d.k + WG_TAPS - 1) / WG_TAPS;
-    p.steps_total = d.B * (d.L / WG_KP);
+    p.steps_total = (int)(((int64_t)d.B * d.L) / WG_KP);
     int split = d.split_k > 0 ? d.split_k : 1;
     if (split > p.steps_total) split = p.steps_total;
     p.steps_per_split = (p.steps_total + split - 1) / split;
@@ -319,5 +360,8 @@ extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream)
     // variant 2: the 32x32x16 form (A/B measurements); default: v_mfma_f32_16x16x32 (higher sustained clock)
     if (d.variant == 2)
         return sp ? launch_wgrad<true, false>(p, (hipStream_t)stream) : launch_wgrad<false, false>(p, (hipStream_t)stream);
+    if (short_seq)
+        return sp ? launch_wgrad<true, true, true>(p, (hipStream_t)stream)
+                  : launch_wgrad<false, true, true>(p, (hipStream_t)stream);
     return sp ? launch_wgrad<true, true>(p, (hipStream_t)stream) : launch_wgrad<false, true>(p, (hipStream_t)stream);
 }

@@ -462,7 +462,9 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     the shape is not covered (the caller then runs the generic TN product)."""
     # bf16: short kernels (k < 7) keep the generic TN product (a chunk of 8 taps would be mostly empty);
     # split-bf16: every k, so that a covered conv bank never needs the fp32 padded input
-    if not _WGRAD_WIN or (k < 7 and dy_lo is None) or L % 64 or Cout % 128 or Cin % 64:
+    # 64 / L whole samples per K step; k < 7 would leave most of the 8-tap chunk empty at these small products
+    short_seq = L in (16, 32) and (B * L) % 64 == 0 and _X3_VARIANT != 2 and k >= 7
+    if not _WGRAD_WIN or (k < 7 and dy_lo is None) or (L % 64 and not short_seq) or Cout % 128 or Cin % 64:
         return False
     d = _lib.WgradDesc()
     d.dy, d.dy_batch_stride, d.dy_row_stride = _p(dy), dy_batch_stride, dy_row_stride
@@ -471,7 +473,7 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     d.x_row_base, d.x_rows = x_row_base, x_rows
     d.B, d.L, d.Cout, d.Cin, d.k = B, L, Cout, Cin, k
     tiles = (Cout // 128) * (Cin // 64) * (-(-k // 8))
-    steps = B * (L // 64)
+    steps = (B * L) // 64
     d.split_k = max(1, min(steps // 16, -(-512 // tiles)))
     d.dw, d.ldw = _p(dw), k * Cin
     d.variant = _X3_VARIANT

@@ -1,9 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2o
 O=gpurun_out/r2o
-timeout -k 10 300 python -m pytest tests/test_gpu_parity_modes.py tests/test_gpu_wgrad.py -x -q -p no:cacheprovider -k "x3 or conv or wgrad" > $O/pytest.log 2>&1; echo "pytest rc=$?"
-tail -3 $O/pytest.log
+timeout -k 10 300 python -m pytest tests/test_gpu_wgrad.py tests/test_gpu_parity_modes.py -x -q -p no:cacheprovider -k "wgrad or conv" > $O/pytest.log 2>&1; echo "pytest rc=$?"
+tail -5 $O/pytest.log
 timeout -k 10 300 python tools/shape_profile.py 512 bf16x3 > $O/shapes_x3.txt 2>&1; echo "shapes rc=$?"
-grep "WX3.*N=    64\|total" $O/shapes_x3.txt | head -18
-APPLECIDER_X3_VARIANT=3 timeout -k 10 300 python tools/shape_profile.py 512 bf16x3 > $O/shapes_x3_v3.txt 2>&1; echo "shapes rc=$?"
-grep "WX3.*N=    64\|total" $O/shapes_x3_v3.txt | head -18
+grep "WGR\|total\|TN " $O/shapes_x3.txt | head -24
