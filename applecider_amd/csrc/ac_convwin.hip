@@ -535,8 +535,12 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int cchunks = d.C / CC;
-    for (int cch = 0; cch < cchunks; ++cch) {
+    // gridDim.y > 1: the channel chunks are split over workgroups (small grids: SpectraNet stage 5 has 32 row
+    // tiles), partial tiles are added to the output with atomics (the host zeroed it unless accumulate)
+    const int cchunks = d.C / CC, csplit = gridDim.y;
+    const int cper = (cchunks + csplit - 1) / csplit;
+    const int c_begin = blockIdx.y * cper, c_end = (c_begin + cper) < cchunks ? (c_begin + cper) : cchunks;
+    for (int cch = c_begin; cch < c_end; ++cch) {
         for (int t0 = 0; t0 < d.k; t0 += TC) {
             const int tc = (d.k - t0) < TC ? (d.k - t0) : TC;   // taps in this chunk (K tiles: one per tap)
             __syncthreads();   // every wave is done with the previous chunk's window and weight stages
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = tn * BN + wn * 64 + c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (d.bias && n < d.N) bias4 = *(const f32x4 *)(d.bias + n);
+    if (d.bias && n < d.N && blockIdx.y == 0) bias4 = *(const f32x4 *)(d.bias + n);
 #pragma unroll
     for (int sa = 0; sa < 2; ++sa) {
         if constexpr (S16) {
@@ -786,8 +790,16 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
             if (n < d.N) {
                 const int64_t row = wm * 64 + sa * 32 + r;
                 f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
-                if (d.accumulate) v += *dst;
-                *dst = v;
+                if (csplit > 1) {
+                    float *df = (float *)dst;
+                    atomicAdd(df, v[0]);
+                    atomicAdd(df + 1, v[1]);
+                    atomicAdd(df + 2, v[2]);
+                    atomicAdd(df + 3, v[3]);
+                } else {
+                    if (d.accumulate) v += *dst;
+                    *dst = v;
+                }
             }
         }
     }
@@ -819,7 +831,21 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
         configured = true;
     }
     const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
-    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16, GR>), dim3(row_tiles * p.tiles_n), dim3(NT), lds, stream, p, TC);
+    // small grids (<= one workgroup per two CUs) with several channel chunks: split the chunks over
+    // gridDim.y and add the partial tiles with atomics
+    int csplit = 1;
+    const int wgs = row_tiles * p.tiles_n, cchunks = d.C / 64;
+    if (wgs <= 128 && cchunks >= 4 && d.ldc == d.N) {
+        csplit = 256 / wgs;
+        if (csplit > cchunks / 2) csplit = cchunks / 2;
+        if (csplit > 4) csplit = 4;
+        if (csplit < 1) csplit = 1;
+    }
+    if (csplit > 1 && !d.accumulate) {
+        hipError_t e = hipMemsetAsync(d.c, 0, (size_t)d.B * d.L * d.ldc * sizeof(float), stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16, GR>), dim3(wgs, csplit), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
