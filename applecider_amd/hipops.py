@@ -493,6 +493,15 @@ def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     extra workgroup pays a fixed prologue + atomic epilogue of a few microseconds)."""
     tiles = max(1, -(-m_out // 128) * -(-n_out // 128))
     nkt = -(-k_red // 64)
+    if x3_mode():
+        # split-bf16 kernel: 32-deep K tiles and ~3x the matrix-core time per tile — workgroups amortise their
+        # prologue over half as many K rows (measured, tools/exp_tn_split.py: 1024x1536x8192 178 -> 139 us,
+        # 512x128x66048 80 -> 72 us, 512x1028x262144 1417 -> 1333 us)
+        split = max(1, min(2048 // tiles, nkt // 32))
+        want = 512 if nkt >= 256 else 256      # short reductions: one workgroup per CU is enough
+        if tiles * split < want:
+            split = max(1, min(want // tiles, nkt // 8))
+        return split
     split = max(1, min(1024 // tiles, nkt // 64))
     if tiles * split < 256:
         split = max(1, min(256 // tiles, nkt // 8))
