@@ -238,3 +238,24 @@ def test_flat_optimizer_state_dict_round_trip_and_rehoming():
     sgd2.load_state_dict(ssd)
     assert not sgd2.first and sgd2.param_groups[0]["lr"] == 0.01
     assert float(sgd2.buf[sgd2.fp.offsets[1]]) == 1.5
+
+
+def test_split_k_rule_by_math_mode():
+    """Host logic only: the split-K factor of the weight-gradient products (hipops._split_for) gives the
+    split-bf16 kernel (32-deep K tiles) about twice the workgroups of the other modes on long reductions,
+    never less than one, and never more workgroups than K tiles allow."""
+    from applecider_amd import hipops as H
+    shapes = [(512, 1028, 262144), (64, 192, 2097152), (1024, 1536, 8192), (384, 1536, 4608), (128, 384, 524288),
+              (512, 128, 66048), (32, 16, 512), (128, 128, 64)]
+    try:
+        H.set_math("bf16x3")
+        x3 = [H._split_for(*s) for s in shapes]
+        H.set_math("f32")
+        f32 = [H._split_for(*s) for s in shapes]
+    finally:
+        H.set_math("f32")
+    for (m, n, k), a, b in zip(shapes, x3, f32):
+        assert a >= 1 and b >= 1
+        assert a <= max(1, -(-k // 64) // 4 + 1) * 8          # at least a few K rows per workgroup
+        assert a >= b                                         # the split-bf16 kernel never splits less
+    assert x3[0] == 2 * f32[0] and x3[2] == 2 * f32[2]
