@@ -626,7 +626,23 @@ def main():
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9   # from the single-stream roofline pass
         out["roofline_hbm"] = {"bound": "hbm", "kernel": "dwconv7x7_fwd_kernel (15x15x96 stage)", "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                               "traffic": None, "launches": d["launches"]}
+                               "traffic": None, "launches": d["launches"],
+                               "measured": "HIP-event bracket around each launch (includes the launch gap of a ~28 us kernel)"}
+        # the same kernel in the committed rocprofv3 kernel statistics of this command (kernel time only)
+        try:
+            import csv
+            stats = os.path.join(ROOT, "profiles", "r02_bench_%s_kernel_stats_%s_single_stream.csv"
+                                 % (args.math, "v4" if args.math == "bf16x3" else "v3"))
+            for row in csv.DictReader(open(stats)):
+                if "dwconv_rows_fwd_kernelILi15" in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    per_launch = d["bytes"] / d["launches"]
+                    out["roofline_hbm"]["rocprof_avg_us"] = round(us, 2)
+                    out["roofline_hbm"]["frac_rocprof"] = round(per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    out["roofline_hbm"]["rocprof_source"] = "profiles/" + os.path.basename(stats) + " (NOT measured in this run)"
+                    break
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_full_model
         from oracle.weights import closed_form_state_dict
