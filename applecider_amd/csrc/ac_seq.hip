@@ -43,48 +43,82 @@ __global__ void embed_fwd_kernel(const float *__restrict__ x, const float *__res
     }
 }
 
-// thread = (channel d, position slot); a workgroup reduces a slab of positions.
+// thread = (channel d = tid % 128, position slot = tid / 128): the two slots walk alternate positions of the
+// workgroup's slab, join through LDS, and one of them adds the slab's partial sums to the gradients
+// (round 1: half the threads idle, a 64-bit division per position and 1024 workgroups x 11 atomics per
+// channel on 1.4 k addresses: 0.33 ms for a 7 -> 128 projection).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const float *__restrict__ dh, const float *__restrict__ x, const float *__restrict__ tw,
     const float *__restrict__ tb, float *__restrict__ dW, float *__restrict__ dbias,
     float *__restrict__ dtw, float *__restrict__ dtb, float *__restrict__ dcls, int B, int L,
     int D, int pos_per_block) {
+    __shared__ float red[12][128];
     const int64_t npos = (int64_t)B * L;
     const int64_t p0 = (int64_t)blockIdx.x * pos_per_block;
     int64_t p1 = p0 + pos_per_block;
     if (p1 > npos) p1 = npos;
-    for (int d = threadIdx.x; d < D; d += 256) {
+    const int lane_d = threadIdx.x & 127, slot = threadIdx.x >> 7;
+    for (int d0 = 0; d0 < D; d0 += 128) {
+        const int d = d0 + lane_d;
+        const bool dv = d < D;
         float aw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float ab = 0.f, atw = 0.f, atb = 0.f;
-        const float w = tw[d], bb = tb[d];
-        for (int64_t p = p0; p < p1; ++p) {
-            const int64_t b = p / L;
-            const int l = (int)(p - b * L);
-            const float g = dh[(b * (L + 1) + l + 1) * D + d];
-            const float *xr = x + p * 8;
+        float ab = 0.f, atw = 0.f, atb = 0.f, acls = 0.f;
+        if (dv) {
+            const float w = tw[d], bb = tb[d];
+            // four positions per trip, their loads issued together (one position per trip left every load's
+            // ~1 us of latency exposed: 128 dependent trips per thread)
+            for (int p = (int)p0 + slot; p < (int)p1; p += 8) {
+                float g[4];
+                const float *xr[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) aw[c] = fmaf(g, xr[c], aw[c]);
-            ab += g;
-            const float tt = xr[0];
-            if (d == 0) {
-                atw = fmaf(g, tt, atw);
-                atb += g;
-            } else {
-                const float cs = cosf(tt * w + bb);
-                atw = fmaf(g * cs, tt, atw);
-                atb = fmaf(g, cs, atb);
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = p + 2 * u;
+                    const bool ok = pp < (int)p1;
+                    const int pc = ok ? pp : p;
+                    const int bq = pc / L, lq = pc - bq * L;
+                    g[u] = dh[((int64_t)bq * (L + 1) + lq + 1) * D + d];
+                    xr[u] = x + (int64_t)pc * 8;
+                    g[u] = ok ? g[u] : 0.f;
+                    // the CLS row of a sample (token 0) is summed by whoever owns the sample's first position
+                    // (one thread walking all B rows made workgroup 0 the whole kernel: 512 dependent misses)
+                    if (ok && lq == 0) acls += dh[((int64_t)bq * (L + 1)) * D + d];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) aw[c] = fmaf(g[u], xr[u][c], aw[c]);
+                    ab += g[u];
+                    const float tt = xr[u][0];
+                    if (d == 0) {
+                        atw = fmaf(g[u], tt, atw);
+                        atb += g[u];
+                    } else {
+                        const float cs = cosf(tt * w + bb);
+                        atw = fmaf(g[u] * cs, tt, atw);
+                        atb = fmaf(g[u], cs, atb);
+                    }
+                }
             }
         }
+        if (slot == 1) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) atomicAdd(&dW[d * 8 + c], aw[c]);
-        atomicAdd(&dbias[d], ab);
-        atomicAdd(&dtw[d], atw);
-        atomicAdd(&dtb[d], atb);
-        if (blockIdx.x == 0) {
-            float s = 0.f;
-            for (int b = 0; b < B; ++b) s += dh[((int64_t)b * (L + 1)) * D + d];
-            atomicAdd(&dcls[d], s);
+            for (int c = 0; c < 8; ++c) red[c][lane_d] = aw[c];
+            red[8][lane_d] = ab;
+            red[9][lane_d] = atw;
+            red[10][lane_d] = atb;
+            red[11][lane_d] = acls;
         }
+        __syncthreads();
+        if (slot == 0 && dv) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) atomicAdd(&dW[d * 8 + c], aw[c] + red[c][lane_d]);
+            atomicAdd(&dbias[d], ab + red[8][lane_d]);
+            atomicAdd(&dtw[d], atw + red[9][lane_d]);
+            atomicAdd(&dtb[d], atb + red[10][lane_d]);
+            const float cl = acls + red[11][lane_d];
+            if (cl != 0.f) atomicAdd(&dcls[d], cl);
+        }
+        __syncthreads();
     }
 }
 
@@ -415,8 +449,9 @@ extern "C" int ac_embed_bwd(const float *dh, const float *x, const float *tw, co
         D <= 0)
         return AC_EINVAL;
     const int64_t npos = (int64_t)B * L;
-    int ppb = 64;
-    while ((npos + ppb - 1) / ppb > 2048) ppb *= 2;
+    if (L < 1 || npos >= (int64_t)1 << 30) return AC_EINVAL;
+    int ppb = 128;
+    while ((npos + ppb - 1) / ppb > 512) ppb *= 2;   // <= 512 workgroups: two per CU, 4x fewer atomics
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((int)((npos + ppb - 1) / ppb)), dim3(256), 0,
                        (hipStream_t)stream, dh, x, tw, tb, dW, dbias, dtw, dtb, dcls, B, L, D, ppb);
     AC_CHECK_LAUNCH();

@@ -1,7 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2o
 O=gpurun_out/r2o
-timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity_modes.py tests/test_gpu_models.py -x -q -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"
+export TMPDIR=/tmp
+timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -x -q -p no:cacheprovider -k "embed or baselinecls or mpt or fusion" > $O/pytest.log 2>&1; echo "pytest rc=$?"
 tail -3 $O/pytest.log
-timeout -k 10 300 python tools/shape_profile.py 512 bf16x3 > $O/shapes_x3.txt 2>&1; echo "shapes rc=$?"
-grep "total" $O/shapes_x3.txt; grep " TN " $O/shapes_x3.txt | awk '{s+=$1} END{print "TN total ms", s}'; grep " TN " $O/shapes_x3.txt | head -12
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode --no-graph --no-branch-streams > $GRAFT_REPO_ROOT/$O/prof.log 2>&1)
+DB=$(find $O/prof -name "*.db" | head -1); python tools/rocpd_stats.py $DB 8 > $O/x3_kernel_stats.csv; rm -rf $O/prof
+grep "embed" $O/x3_kernel_stats.csv | cut -c1-160
