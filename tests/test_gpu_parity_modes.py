@@ -203,7 +203,9 @@ def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (2, 128, 128, 64, (3, 15, 61)),
                                              (1, 256, 256, 128, (7, 13, 31)), (2, 64, 128, 256, (3, 15, 61)),
-                                             (8, 64, 128, 256, (3, 11, 31)), (32, 16, 512, 128, (3, 7, 13))])
+                                             (8, 64, 128, 256, (3, 11, 31)), (32, 16, 512, 128, (3, 7, 13)),
+                                             # whole-sample tiles + the two-group (N <= 64) window kernel
+                                             (8, 64, 64, 128, (3, 11, 31)), (32, 16, 64, 128, (3, 7, 13))])
 def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
     """The SpectraNetBlock conv bank in split-bf16 mode — forward and input gradient on the window
     kernel over (hi, lo) planes (fused single launch with chunked windows, or three passes of the bf16
