@@ -620,6 +620,42 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
     }
 }
 
+// g = dy * act'(aux) and out[c] += sum_r g[r, c] in one pass: the gradient in front of an activated Linear
+// layer is needed as the operand of two products AND, summed over rows, as the bias gradient (fp32 data
+// flow: f32 and split-bf16 modes; the bf16 mode has cast_colsum).  Lane = column pair, 4 row phases.
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float *__restrict__ dy,
+                                                             const float *__restrict__ aux, float *__restrict__ g,
+                                                             int64_t ld, float *__restrict__ out, int64_t rows,
+                                                             int cols, int kind, int rows_per_block) {
+    __shared__ float part[4][128];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 128 + 2 * cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + ph; r < r1; r += 4) {
+            const float2 d = *(const float2 *)(dy + r * ld + c), x = *(const float2 *)(aux + r * ld + c);
+            float2 v;
+            v.x = d.x * ac_dact(x.x, kind);
+            v.y = d.y * ac_dact(x.y, kind);
+            a0 += v.x;
+            a1 += v.y;
+            *(float2 *)(g + r * ld + c) = v;
+        }
+    }
+    part[ph][2 * cl] = a0;
+    part[ph][2 * cl + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = blockIdx.y * 128 + threadIdx.x;
+        if (cc < cols)
+            atomicAdd(&out[cc], (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                    (part[2][threadIdx.x] + part[3][threadIdx.x]));
+    }
+}
+
 // bf16 input (the bf16 hidden gradient the fused MLP backward keeps): a lane owns a column PAIR
 // (one dword), a wave reads 256 contiguous bytes per row, fp32 sums.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short *__restrict__ x,
@@ -934,6 +970,26 @@ extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, 
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 63) / 64));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows,
                        cols, rpb);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+extern "C" int ac_act_bwd_colsum(const float *dy, const float *aux, float *g, int64_t ld, float *out,
+                                 int64_t rows, int32_t cols, int32_t act, int32_t accumulate,
+                                 ac_stream_t stream) {
+    if (!dy || !aux || !g || !out || rows < 0 || cols <= 0) return AC_EINVAL;
+    if ((cols & 1) || (ld & 1) || ((uintptr_t)dy & 7u) || ((uintptr_t)aux & 7u) || ((uintptr_t)g & 7u))
+        return AC_EALIGN;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    if (rows == 0) return AC_OK;
+    int rpb = 128;
+    while ((rows + rpb - 1) / rpb > 4096) rpb *= 2;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 127) / 128));
+    hipLaunchKernelGGL(act_bwd_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, aux, g, ld, out,
+                       rows, cols, act, rpb);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

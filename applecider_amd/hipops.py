@@ -655,13 +655,21 @@ class _Linear(Function):
             dcs = torch.zeros_like(colscale)
             _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), None, _p(dcs),
                                                  None, M, N, _stream()), "ac_layerscale_bwd")
-        elif ctx.act != ACT_NONE:
+        bias_done = False
+        if colscale is None and ctx.act != ACT_NONE:
             g = torch.empty_like(dy2)
-            _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
-                       "ac_act_bwd")
+            bsink = _sink(ctx.bp) if (not ctx.b16 and ctx.has_b and ctx.needs_input_grad[2] and N % 2 == 0) else None
+            if bsink is not None:
+                # fp32 data flow: activation backward and the bias gradient (into its sink) in one pass
+                _lib.check(_lib_().ac_act_bwd_colsum(_p(dy2), _p(aux), _p(g), N, _p(bsink), M, N, ctx.act, 1,
+                                                     _stream()), "ac_act_bwd_colsum")
+                _grad_written(ctx.bp)
+                bias_done = True
+            else:
+                _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
+                           "ac_act_bwd")
         dx = dw = db = None
         g16 = None
-        bias_done = False
         if ctx.b16:
             bsink = _sink(ctx.bp) if (ctx.has_b and ctx.needs_input_grad[2]) else None
             if bsink is not None and N % 2 == 0:
