@@ -653,9 +653,13 @@ class _Linear(Function):
             # y = pre*gamma (+res): dpre = dy*gamma ; dgamma = sum_m dy*pre
             g = torch.empty_like(dy2)
             dcs = torch.zeros_like(colscale)
+            # the bias gradient of the Linear under the scale comes out of the same pass (into its sink)
+            lsink = _sink(ctx.bp) if (not ctx.b16 and ctx.has_b and ctx.needs_input_grad[2]) else None
             _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), None, _p(dcs),
-                                                 None, M, N, _stream()), "ac_layerscale_bwd")
-        bias_done = False
+                                                 _p(lsink), M, N, _stream()), "ac_layerscale_bwd")
+            if lsink is not None:
+                _grad_written(ctx.bp)
+        bias_done = colscale is not None and lsink is not None
         if colscale is None and ctx.act != ACT_NONE:
             g = torch.empty_like(dy2)
             bsink = _sink(ctx.bp) if (not ctx.b16 and ctx.has_b and ctx.needs_input_grad[2] and N % 2 == 0) else None
