@@ -151,7 +151,7 @@ SIGNATURES = {
     "ac_adam_flat_dev": [_P, _P, _P, _P, C.POINTER(AdamSeg), _I32, _P, _P, _P],
     "ac_step_advance": [_P, _P],
     "ac_sgd_flat": [_P, _P, _P, _I64, _F, _F, _F, _I32, _P],
-    "ac_act_bwd_colsum": [_P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P],
+    "ac_act_bwd_colsum": [_P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _F, _U64, _P, _P],
     "ac_tower_blocks_fwd": [C.POINTER(TowerDesc), _I32, _I32, _F, _I32, _U64, _P, _P],
     "ac_tower_blocks_bwd": [C.POINTER(TowerDesc), _I32, _I32, _F, _I32, _U64, _P, _P],
     "ac_sumsq": [_P, _I64, _P, _P],

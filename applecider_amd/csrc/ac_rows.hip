@@ -626,8 +626,11 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float *__restrict__ dy,
                                                              const float *__restrict__ aux, float *__restrict__ g,
                                                              int64_t ld, float *__restrict__ out, int64_t rows,
-                                                             int cols, int kind, int rows_per_block) {
+                                                             int cols, int kind, int rows_per_block, float drop_p,
+                                                             uint64_t seed, const uint64_t *stepp) {
     __shared__ float part[4][128];
+    seed = ac_step_seed(seed, stepp);
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int c = blockIdx.y * 128 + 2 * cl;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -636,10 +639,17 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float *__rest
     float a0 = 0.f, a1 = 0.f;
     if (c < cols) {
         for (int64_t r = r0 + ph; r < r1; r += 4) {
-            const float2 d = *(const float2 *)(dy + r * ld + c), x = *(const float2 *)(aux + r * ld + c);
-            float2 v;
-            v.x = d.x * ac_dact(x.x, kind);
-            v.y = d.y * ac_dact(x.y, kind);
+            float2 v = *(const float2 *)(dy + r * ld + c);
+            if (drop_p > 0.f) {   // the forward epilogue's mask: element index r * cols + c (ld == cols there)
+                const uint64_t i0 = (uint64_t)r * (uint64_t)cols + (uint64_t)c;
+                v.x = ac_rand01(seed, i0) >= drop_p ? v.x * inv_keep : 0.f;
+                v.y = ac_rand01(seed, i0 + 1) >= drop_p ? v.y * inv_keep : 0.f;
+            }
+            if (aux) {
+                const float2 x = *(const float2 *)(aux + r * ld + c);
+                v.x *= ac_dact(x.x, kind);
+                v.y *= ac_dact(x.y, kind);
+            }
             a0 += v.x;
             a1 += v.y;
             *(float2 *)(g + r * ld + c) = v;
@@ -975,9 +985,11 @@ extern "C" int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, 
 }
 
 extern "C" int ac_act_bwd_colsum(const float *dy, const float *aux, float *g, int64_t ld, float *out,
-                                 int64_t rows, int32_t cols, int32_t act, int32_t accumulate,
-                                 ac_stream_t stream) {
-    if (!dy || !aux || !g || !out || rows < 0 || cols <= 0) return AC_EINVAL;
+                                 int64_t rows, int32_t cols, int32_t act, int32_t accumulate, float drop_p,
+                                 uint64_t drop_seed, const uint64_t *step, ac_stream_t stream) {
+    if (!dy || !g || !out || rows < 0 || cols <= 0 || drop_p < 0.f || drop_p >= 1.f) return AC_EINVAL;
+    if (!aux && act != AC_ACT_NONE) return AC_EINVAL;
+    if (drop_p > 0.f && ld != cols) return AC_EINVAL;   // the mask index is the forward product's m * N + n
     if ((cols & 1) || (ld & 1) || ((uintptr_t)dy & 7u) || ((uintptr_t)aux & 7u) || ((uintptr_t)g & 7u))
         return AC_EALIGN;
     if (!accumulate) {
@@ -989,7 +1001,7 @@ extern "C" int ac_act_bwd_colsum(const float *dy, const float *aux, float *g, in
     while ((rows + rpb - 1) / rpb > 4096) rpb *= 2;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 127) / 128));
     hipLaunchKernelGGL(act_bwd_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, aux, g, ld, out,
-                       rows, cols, act, rpb);
+                       rows, cols, act, rpb, drop_p, drop_seed, step);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }

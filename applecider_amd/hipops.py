@@ -601,10 +601,12 @@ def colsum(x2d_ptr, ld, rows, cols, device) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- Linear
 class _Linear(Function):
-    """y = act(x @ w.T + b) [* colscale] [+ residual]   (nn.Linear + fused epilogue)."""
+    """y = [drop](act(x @ w.T + b) [* colscale]) [+ residual]   (nn.Linear + fused epilogue).
+    drop_p > 0 (fp32 data flow only): nn.Dropout on the product's output inside the GEMM epilogue; the
+    backward applies the same mask in the pass that also forms act' and the bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, residual, colscale):
+    def forward(ctx, x, w, b, act, residual, colscale, drop_p=0.0):
         ctx.x16only = _is16only(x)   # producer handed the activation over in bf16 only
         x = _chk(x, "x", allow16=True)
         w = _chk(w, "w")
@@ -624,6 +626,14 @@ class _Linear(Function):
         if ctx.x16only and not ctx.b16:
             raise RuntimeError("bf16-only activation reached a product that is not on the bf16 path")
         x16 = None
+        ctx.drop_p, ctx.drop_seed = float(drop_p), 0
+        if drop_p > 0.0:
+            if ctx.b16 or colscale is not None or N % 2 or act not in (ACT_NONE, ACT_RELU, ACT_GELU):
+                raise ValueError("fused dropout: fp32 data flow, even width, act none / relu / gelu, no layer scale")
+            ctx.drop_seed = next_seed()
+            if act == ACT_RELU and pre is None and need_grad:
+                pre = torch.empty_like(y)      # y is post-dropout: keep the pre-activation for act'
+                save_pre = True
         if ctx.b16:
             x16, w16 = cast16_act(x, K), cast16_w(w)
             gemm(AC_GEMM_NT, M, N, K, mat(_p(x16), K), mat(_p(w16), K), mat(_p(y), N), bias=b,
@@ -631,7 +641,8 @@ class _Linear(Function):
                  math=_lib.MATH_BF16_IN)
         else:
             gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
-                 pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N)
+                 pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
+                 drop_p=ctx.drop_p, drop_seed=ctx.drop_seed)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.shape_x = x.shape
         ctx.has_b = b is not None
@@ -660,19 +671,27 @@ class _Linear(Function):
             if lsink is not None:
                 _grad_written(ctx.bp)
         bias_done = colscale is not None and lsink is not None
-        if colscale is None and ctx.act != ACT_NONE:
+        db_tmp = None
+        if colscale is None and (ctx.act != ACT_NONE or ctx.drop_p > 0.0):
             g = torch.empty_like(dy2)
-            bsink = _sink(ctx.bp) if (not ctx.b16 and ctx.has_b and ctx.needs_input_grad[2] and N % 2 == 0) else None
-            if bsink is not None:
-                # fp32 data flow: activation backward and the bias gradient (into its sink) in one pass
-                _lib.check(_lib_().ac_act_bwd_colsum(_p(dy2), _p(aux), _p(g), N, _p(bsink), M, N, ctx.act, 1,
-                                                     _stream()), "ac_act_bwd_colsum")
-                _grad_written(ctx.bp)
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            bsink = _sink(ctx.bp) if (not ctx.b16 and want_b and N % 2 == 0) else None
+            if bsink is not None or ctx.drop_p > 0.0:
+                # fp32 data flow: dropout mask, activation backward and the bias gradient in one pass
+                tgt = bsink
+                if tgt is None:
+                    tgt = db_tmp = torch.zeros(N, device=dy.device, dtype=torch.float32)
+                _lib.check(_lib_().ac_act_bwd_colsum(_p(dy2), _p(aux) if ctx.act != ACT_NONE else None, _p(g), N,
+                                                     _p(tgt), M, N, ctx.act, 1, ctx.drop_p, ctx.drop_seed,
+                                                     _p(_STEP_DEV), _stream()), "ac_act_bwd_colsum")
+                if bsink is not None:
+                    _grad_written(ctx.bp)
                 bias_done = True
             else:
                 _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
                            "ac_act_bwd")
-        dx = dw = db = None
+        dx = dw = None
+        db = db_tmp if (db_tmp is not None and ctx.has_b and ctx.needs_input_grad[2]) else None
         g16 = None
         if ctx.b16:
             bsink = _sink(ctx.bp) if (ctx.has_b and ctx.needs_input_grad[2]) else None
@@ -725,7 +744,7 @@ class _Linear(Function):
             else:
                 db = colsum(_p(g), N, M, N, dy.device)
         dres = dy if ctx.has_res else None
-        return dx, dw, db, None, dres, dcs
+        return dx, dw, db, None, dres, dcs, None
 
 
 class _MLP(Function):
@@ -877,18 +896,19 @@ def mlp(x, w1, b1, w2, b2, act, p1=0.0, p2=0.0, training=True, residual=None, co
     if (bf16_operands() and K % 8 == 0 and Hd % 8 == 0 and N % 8 == 0 and _big(M, Hd, K)
             and _big(M, N, Hd) and act_code in (ACT_GELU, ACT_RELU) and x.is_cuda):
         return _MLP.apply(x, w1, b1, w2, b2, act_code, float(p1), float(p2), residual, colscale)
-    h = linear(x, w1, b1, act=act_code)
-    if p1 > 0:
-        h = dropout(h, p1, True)
-    if p2 > 0:
-        y = dropout(linear(h, w2, b2, colscale=colscale), p2, True)
+    h = linear(x, w1, b1, act=act_code, drop_p=p1)
+    return linear(h, w2, b2, residual=residual, colscale=colscale, drop_p=p2)
+
+
+def linear(x, w, b=None, act=None, residual=None, colscale=None, drop_p: float = 0.0):
+    """drop_p > 0: dropout on the product's output (before the residual), fused into the product in the fp32
+    data flow; the caller passes 0 in eval mode."""
+    act_code = ACT_CODES[act] if not isinstance(act, int) else act
+    if drop_p > 0.0 and (bf16_operands() or colscale is not None or w.shape[0] % 2 or not x.is_cuda):
+        # not covered by the fused epilogue here: product, then the dropout kernel, then the residual
+        y = dropout(_Linear.apply(x, w, b, act_code, None, colscale, 0.0), drop_p, True)
         return add(residual, y) if residual is not None else y
-    return linear(h, w2, b2, residual=residual, colscale=colscale)
-
-
-def linear(x, w, b=None, act=None, residual=None, colscale=None):
-    return _Linear.apply(x, w, b, ACT_CODES[act] if not isinstance(act, int) else act, residual,
-                         colscale)
+    return _Linear.apply(x, w, b, act_code, residual, colscale, float(drop_p))
 
 
 # --------------------------------------------------------------------------- LayerNorm

@@ -85,10 +85,8 @@ class EncoderLayer(nn.Module):
         drop = self.training and self.p > 0
         qkv = H.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         a = H.mha(qkv, pad_u8, self.n_heads, self.p, self.training)
-        if drop:
-            x = H.add(x, H.dropout(sa.out_proj(a), self.p, True))
-        else:
-            x = sa.out_proj(a, residual=x)
+        # x + dropout1(out_proj(attention)): one product with dropout and residual in its epilogue
+        x = H.linear(a, sa.out_proj.weight, sa.out_proj.bias, residual=x, drop_p=self.p if drop else 0.0)
         x = self.norm1(x)
         l1, l2 = self.linear1, self.linear2
         x = H.mlp(x, l1.weight, l1.bias, l2.weight, l2.bias, "relu", p1=self.p, p2=self.p,

@@ -224,12 +224,15 @@ int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
 /* out[n] (+)= sum_m x[m,n]  — bias gradients. */
 int ac_colsum(const float *x, int64_t ldx, float *out, int64_t rows, int32_t cols,
               int32_t accumulate, ac_stream_t stream);
-/* g = dy * act'(aux) elementwise AND out[c] (+)= sum_r g[r, c] in one pass over [rows, cols] (row stride ld for
- * all three): the backward entry of an activated Linear (astrominn.py:19-28 heads, timm ConvNeXt fc1 + GELU,
- * nn.TransformerEncoderLayer linear1 + ReLU) needs both.  aux as in ac_act_bwd (pre-activation for GELU /
- * ReLU, output for sigmoid / tanh).  cols and ld even, pointers 8-byte aligned. */
+/* g = dropmask * dy * act'(aux) elementwise AND out[c] (+)= sum_r g[r, c] in one pass over [rows, cols] (row
+ * stride ld for all three): the backward entry of an activated Linear (astrominn.py:19-28 heads, timm ConvNeXt
+ * fc1 + GELU, nn.TransformerEncoderLayer linear1 + ReLU + dropout, linear2 + dropout) needs both.  aux as in
+ * ac_act_bwd (pre-activation for GELU / ReLU, output for sigmoid / tanh; NULL with act none).  drop_p > 0:
+ * the mask ac_gemm's epilogue drew in the forward product (same seed / step counter, element index
+ * m * cols + n, ld == cols), scaled by 1/(1-p).  cols and ld even, pointers 8-byte aligned. */
 int ac_act_bwd_colsum(const float *dy, const float *aux, float *g, int64_t ld, float *out, int64_t rows,
-                      int32_t cols, int32_t act, int32_t accumulate, ac_stream_t stream);
+                      int32_t cols, int32_t act, int32_t accumulate, float drop_p, uint64_t drop_seed,
+                      const uint64_t *step, ac_stream_t stream);
 /* y16 = bf16(x) and out[n] (+)= sum_m x[m,n] in one pass (cols, ldx, ldy even). */
 int ac_cast_bf16_colsum(const float *x, int64_t ldx, void *y16, int64_t ldy, float *out,
                         int64_t rows, int32_t cols, int32_t accumulate, ac_stream_t stream);

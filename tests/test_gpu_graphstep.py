@@ -217,3 +217,37 @@ def test_graph_replays_draw_new_masks_and_recapture_on_lr_change(dev):
     assert not torch.equal(m.optimizer.fp.flat, p0)
     with pytest.raises(ValueError):
         step(tuple(t[:4] for t in batches[0]))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("act,with_res", [("relu", False), ("gelu", False), (None, True)])
+def test_linear_fused_dropout_equals_product_then_dropout(dev, mode, act, with_res):
+    """fp32 data flow: nn.Dropout inside the product's epilogue (and its mask inside the one backward pass that
+    also forms act' and the bias gradient) == product, then ac_dropout, then the residual add, under the same
+    seed — outputs bit-identical, every gradient equal (encoder layer: Time2Vec.py:96-101, dropout1 / dropout2)."""
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    torch.manual_seed(7)
+    M, K, N = 516, 128, 512
+    x0 = torch.randn(M, K, device=dev)
+    w0 = (torch.randn(N, K, device=dev) * 0.1)
+    b0 = torch.randn(N, device=dev)
+    r0 = torch.randn(M, N, device=dev)
+    go = torch.randn(M, N, device=dev)
+    res = {}
+    for fused in (True, False):
+        x, w, b, r = (t.clone().requires_grad_() for t in (x0, w0, b0, r0))
+        H._seed_counter = itertools.count(9000)
+        if fused:
+            y = H.linear(x, w, b, act=act, residual=r if with_res else None, drop_p=0.3)
+        else:
+            y = H.dropout(H.linear(x, w, b, act=act), 0.3, True)
+            if with_res:
+                y = H.add(r, y)
+        gr = torch.autograd.grad(y, [x, w, b] + ([r] if with_res else []), go)
+        res[fused] = (y.detach(), gr)
+    assert torch.equal(res[True][0], res[False][0])
+    frac = (res[True][0] == (r0 if with_res else 0)).float().mean().item()
+    assert 0.25 < frac < (0.75 if act == "relu" else 0.35), frac        # ~30 % dropped (+ ReLU zeros)
+    for a, b_ in zip(res[True][1], res[False][1]):
+        assert _rel(a, b_) <= 2e-6
