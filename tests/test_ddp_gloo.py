@@ -259,3 +259,16 @@ def test_split_k_rule_by_math_mode():
         assert a <= max(1, -(-k // 64) // 4 + 1) * 8          # at least a few K rows per workgroup
         assert a >= b                                         # the split-bf16 kernel never splits less
     assert x3[0] == 2 * f32[0] and x3[2] == 2 * f32[2]
+
+
+def test_public_header_is_plain_c():
+    """include/applecider_hip.h is the FFI contract: it must compile as C99 and as C++ on its own (no HIP or
+    torch types in any signature)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "applecider_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-Wall", "-Werror", hdr], check=True)
