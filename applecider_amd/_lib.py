@@ -156,6 +156,8 @@ SIGNATURES = {
     "ac_tower_blocks_bwd": [C.POINTER(TowerDesc), _I32, _I32, _F, _I32, _U64, _P, _P],
     "ac_sumsq": [_P, _I64, _P, _P],
     "ac_clip_coef": [_P, _F, _P, _P],
+    "ac_ceil_copy": [_P, _P, _I64, _P],
+    "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
 }
 ABI_VERSION = 2
 _RESTYPES = {"ac_strerror": C.c_char_p}

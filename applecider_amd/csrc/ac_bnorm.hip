@@ -42,15 +42,21 @@ __device__ __forceinline__ void col_reduce2(F &&rowfn, float *out_u, float *out_
 __global__ __launch_bounds__(256) void bn_moments_kernel(const float *__restrict__ x, int64_t ld,
                                                          float *__restrict__ sum, float *__restrict__ sumsq,
                                                          int64_t rows, int cols, int rpb) {
+    // SHIFTED moments: sums of (x - K) and (x - K)^2 with K = the column's first row.  E[x^2] - mean^2 in one
+    // fp32 pass cancels catastrophically when |mean| >> std (2M rows at the benchmark shape); about a value of
+    // the column itself the two terms are of the size of the variance, as in a two-pass scheme, at one read.
+    const int cb = blockIdx.y * 256 + 4 * (threadIdx.x & 63);
+    f32x4 K = {0.f, 0.f, 0.f, 0.f};
+    if (cb < cols) K = *(const f32x4 *)(x + cb);
     col_reduce2([&](int64_t r, int c, f32x4 &su, f32x4 &sv) {
-        const f32x4 v = *(const f32x4 *)(x + r * ld + c);
+        const f32x4 v = *(const f32x4 *)(x + r * ld + c) - K;
         su += v;
         sv += v * v;
     }, sum, sumsq, rows, cols, rpb);
 }
 
 // per channel: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running statistics
-__global__ void bn_finalize_fwd_kernel(const float *sum, const float *sumsq, const float *gamma,
+__global__ void bn_finalize_fwd_kernel(const float *x_row0, const float *sum, const float *sumsq, const float *gamma,
                                        const float *beta, float *running_mean, float *running_var,
                                        float *mean, float *rstd, float *scale, float *shift, int cols,
                                        float n, float eps, float momentum, int training) {
@@ -58,8 +64,9 @@ __global__ void bn_finalize_fwd_kernel(const float *sum, const float *sumsq, con
     if (c >= cols) return;
     float m, var;
     if (training) {
-        m = sum[c] / n;
-        var = fmaxf(sumsq[c] / n - m * m, 0.f);   // biased, as the normalisation uses it
+        const float d = sum[c] / n;                 // mean of (x - K), K = x[0][c] (bn_moments_kernel)
+        m = x_row0[c] + d;
+        var = fmaxf(sumsq[c] / n - d * d, 0.f);     // biased, as the normalisation uses it
         if (running_mean) {
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
@@ -98,13 +105,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
                                                             const float *__restrict__ x, int64_t ld,
                                                             const float *__restrict__ scale,
                                                             const float *__restrict__ shift,
+                                                            const float *__restrict__ mean,
                                                             float *__restrict__ sum_dz, float *__restrict__ sum_dzx,
                                                             int64_t rows, int cols, int act, int rpb) {
     const int cb = blockIdx.y * 256 + 4 * (threadIdx.x & 63);
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc;
     if (cb < cols) {
         sc = *(const f32x4 *)(scale + cb);
         sh = *(const f32x4 *)(shift + cb);
+        mu = *(const f32x4 *)(mean + cb);
     }
     col_reduce2([&](int64_t r, int c, f32x4 &su, f32x4 &sv) {
         const f32x4 g = *(const f32x4 *)(dy + r * lddy + c), v = *(const f32x4 *)(x + r * ld + c);
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
         for (int j = 0; j < 4; ++j) {
             const float dz = bn_dz(g[j], v[j], sc[j], sh[j], act);
             su[j] += dz;
-            sv[j] += dz * v[j];
+            sv[j] += dz * (v[j] - mu[j]);   // centred: sum dz*x - mean*sum dz cancels when |mean| >> std
         }
     }, sum_dz, sum_dzx, rows, cols, rpb);
 }
@@ -124,7 +133,7 @@ __global__ void bn_finalize_bwd_kernel(const float *sum_dz, const float *sum_dzx
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     const float m = mean[c], rs = rstd[c], a = gamma[c] * rs;
-    const float s1 = sum_dz[c], s2 = rs * (sum_dzx[c] - m * s1);   // sum dz, sum dz*xhat
+    const float s1 = sum_dz[c], s2 = rs * sum_dzx[c];   // sum dz, sum dz*xhat (the reduction is centred)
     dgamma[c] += s2;
     dbeta[c] += s1;
     A[c] = a;
@@ -183,7 +192,7 @@ extern "C" int ac_batchnorm_fwd(const float *x, int64_t ld, const float *gamma, 
         dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 255) / 256));
         hipLaunchKernelGGL(bn_moments_kernel, grid, dim3(256), 0, stream, x, ld, sums, sums + cols, rows, cols, rpb);
     }
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, sums,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, x, sums,
                        sums ? sums + cols : nullptr, gamma, beta, running_mean, running_var, mean, rstd, scale, shift,
                        cols, (float)rows, eps, momentum, training);
     int64_t g = (rows * (cols / 4) + 255) / 256;
@@ -209,7 +218,7 @@ extern "C" int ac_batchnorm_bwd(const float *dy, int64_t lddy, const float *x, i
     float *s1 = work, *s2 = work + cols, *A = work + 2 * cols, *Bc = work + 3 * cols, *C0 = work + 4 * cols;
     const int rpb = rows_per_block(rows);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)((cols + 255) / 256));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, stream, dy, lddy, x, ld, scale, shift, s1, s2, rows,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, stream, dy, lddy, x, ld, scale, shift, mean, s1, s2, rows,
                        cols, act, rpb);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, s1, s2, gamma, mean,
                        rstd, A, Bc, C0, dgamma, dbeta, cols, (float)rows, training);

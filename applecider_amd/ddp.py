@@ -174,7 +174,9 @@ class GradBuckets:
     def finish(self):
         """Call after backward(): completes the exchange and leaves the AVERAGED gradient in the
         flat buffer.  No host synchronisation on GPU (stream waits only)."""
-        if self.world == 1 and self.ops is None:
+        # single process without hooks (no process group, no explicit stream_ops): nothing to exchange —
+        # also on a GPU, where `ops` exists but neither hooks nor a communicator do
+        if self.world == 1 and not self._hooks:
             return
         for b in range(len(self.buckets)):
             self._launch(b)

@@ -39,6 +39,50 @@ def _default_step(model, batch):
     return out["loss"] if isinstance(out, dict) else out
 
 
+def _accumulate_node(p):
+    """The AccumulateGrad node of a leaf: autograd keeps ONE per parameter for as long as anything references
+    it (a live autograd graph does) and builds a new one otherwise."""
+    fn = p.view_as(p).grad_fn
+    return fn.next_functions[0][0] if fn is not None and fn.next_functions else None
+
+
+def stale_autograd_parameters(params, limit: int = 4):
+    """Names / indices of parameters whose AccumulateGrad node is held alive by an autograd graph of an
+    EARLIER step (a kept `loss`, a saved output with a grad_fn ...).  Such a node is bound to the stream its
+    step ran on; replaying it inside a capture pulls that stream into the capture, which on ROCm 7.2 ends
+    in a segfault inside hipStreamEndCapture rather than in an error.
+
+    Detection does not depend on autograd's "AccumulateGrad node's stream" warning (the fused model
+    silences it process-wide, models/applecider.py `_streams`): a token is written into the node's metadata
+    dict, the Python reference is dropped, and the node is looked up again — the token is still there only if
+    something else kept the C++ node alive."""
+    token = object()
+    stale = []
+    for i, p in enumerate(params):
+        if not (torch.is_tensor(p) and p.requires_grad and p.is_leaf):
+            continue
+        n = _accumulate_node(p)
+        if n is None:
+            continue
+        n.metadata["_ac_capture_probe"] = token
+        del n
+        n = _accumulate_node(p)
+        alive = n is not None and n.metadata.get("_ac_capture_probe") is token
+        if n is not None:
+            n.metadata.pop("_ac_capture_probe", None)
+        del n
+        if alive:
+            stale.append(i)
+            if len(stale) >= limit:
+                break
+    return stale
+
+
+_STALE_MSG = ("GraphedTrainStep: an autograd graph of an earlier eager step is still alive (e.g. a kept `loss` "
+              "tensor, parameters {idx}); drop it (`del loss` / `.detach()`) before building or re-capturing "
+              "the graphed step")
+
+
 def _hyper_signature(opt):
     sig = []
     for g in getattr(opt, "param_groups", []):
@@ -119,6 +163,7 @@ class GraphedTrainStep:
         return self.step_fn(self.model, self.static)
 
     def _capture(self, restore_state=True):
+        self._check_no_stale_graph()
         snap = self._snapshot() if restore_state else None
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -136,13 +181,10 @@ class GraphedTrainStep:
                 # that step's AccumulateGrad nodes alive, which are bound to the stream of that step and
                 # would pull the default stream into the capture (on ROCm 7.2 that ends in a segfault
                 # inside hipStreamEndCapture, not in an error)
-                raise RuntimeError("GraphedTrainStep: an autograd graph of an earlier eager step is still alive "
-                                   "(e.g. a kept `loss` tensor); drop it (`del loss` / `.detach()`) before "
-                                   "building the graphed step")
+                raise RuntimeError(_STALE_MSG.format(idx="reported by autograd"))
             warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = self._one()
+        self._check_no_stale_graph()    # the warm-up's own graphs are gone (its losses were dropped)
+        loss = self._record()
         if not (torch.is_tensor(loss) and loss.is_cuda):
             raise TypeError("step_fn must return the loss as a CUDA tensor (no host sync inside a captured step)")
         torch.cuda.synchronize()
@@ -151,9 +193,25 @@ class GraphedTrainStep:
             self.opt.step_count -= 1
         if snap is not None:
             self._restore(snap)
-        self.graph, self.loss = g, loss.detach()   # same storage, no autograd graph kept alive
+        self.graph, self.loss = self._graph_new, loss.detach()   # same storage, no autograd graph kept alive
+        self._graph_new = None
         self._sig = _hyper_signature(self.opt)
         self.captures += 1
+        self._invalidate_weight_copies()
+
+    def _check_no_stale_graph(self):
+        stale = stale_autograd_parameters(list(self.model.parameters()))
+        if stale:
+            raise RuntimeError(_STALE_MSG.format(idx=stale))
+
+    def _record(self):
+        """The capture itself (a separate method so that a test can stand in for it: a guard that misses
+        must fail an assertion there, not reach hipStreamEndCapture)."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._one()
+        self._graph_new = g
+        return loss
 
     # ------------------------------------------------------------------ replay
     def load(self, batch: Sequence[torch.Tensor]):
@@ -175,4 +233,13 @@ class GraphedTrainStep:
         self.graph.replay()
         if hasattr(self.opt, "step_count"):
             self.opt.step_count += 1
+        self._invalidate_weight_copies()
         return self.loss
+
+    def _invalidate_weight_copies(self):
+        """The captured optimizer updates the parameters through raw pointers: no `_version` bump tells the
+        host-side weight caches (16-bit mirrors, the (hi, lo) conv planes of bf16x3 mode) that they are stale.
+        Eager `step()` marks them itself; a replay must too, or an eager forward between replays (validation
+        after a graphed epoch) would keep using the copies of its first call."""
+        self.opt.fp.mirror_dirty = True
+        H.clear_step_cache()

@@ -519,6 +519,21 @@ int ac_step_advance(uint64_t *counter_dev, ac_stream_t stream);
 int ac_sumsq(const float *x, int64_t n, float *out, ac_stream_t stream);
 int ac_clip_coef(const float *sumsq, float max_norm, float *coef, ac_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Measured ceilings of the box (bench.py `ceilings`; SURVEY.md section 8d asks for the on-box copy rate
+ * and the register-resident MFMA rate beside the vendor peaks).  They replace nothing of the reference:
+ * measurement utilities on the same C ABI so that the bench needs no second library.
+ *   ac_ceil_copy: dst[0..bytes) = src[0..bytes), 16 bytes per lane, grid-stride (bytes % 16 == 0).
+ *   ac_ceil_mfma: `workgroups` x `waves_per_wg` (4 = one wave per SIMD, 8 = two) waves each run `iters`
+ *       rounds of 16 x v_mfma_f32_16x16x32 (shape 0) or 8 x v_mfma_f32_32x32x16 (shape 1) on 16-bit
+ *       operands taken once from `ops` (64*8*64*64 values of the library's operand format) into
+ *       registers; FLOP = workgroups * waves_per_wg * iters * 16 * 2*16*16*32.  `out` receives one
+ *       float per thread (the accumulator sums: keeps the work alive).
+ */
+int ac_ceil_copy(const void *src, void *dst, int64_t bytes, ac_stream_t stream);
+int ac_ceil_mfma(const void *ops, float *out, int32_t shape, int32_t workgroups, int32_t waves_per_wg,
+                 int32_t iters, ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,3 +170,79 @@ def test_two_ranks_one_gpu_gradient_average(dev, overlap, sinks, fused):
                                            f"n_bad {(err > tol * scale).sum()}, local-vs-want "
                                            f"{np.abs(ref[r].cpu().numpy() - want).max():.3e}")
     assert np.abs(got[0][0] - got[1][0]).max() == 0.0  # replicas hold identical averaged gradients
+
+
+def _rccl_worker(port, q):
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",
+                           "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        from applecider_amd import ddp
+        from applecider_amd import hipops as H
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        assert ddp.rccl_ranks() == 1
+        m = _Fused(dev)
+        assert m.m.branch_streams
+        opt = m.this_optimizer.prepare()
+        ddp.broadcast_parameters(opt.fp)          # world 1: no collective, must not raise
+        batch = _batch(100, dev, True)
+        # reference gradient: the same step without buckets
+        opt.zero_grad()
+        m.loss(batch).backward()
+        torch.cuda.synchronize()
+        want = opt.fp.grad.clone()
+        # the bucket path as the N > 1 job runs it: hooks + gradient sinks, exchange stream, async RCCL
+        # all-reduce per bucket, h.wait() + stream join + device-side averaging in finish()
+        gb = ddp.GradBuckets(opt.fp, bucket_bytes=8 << 20, overlap=True, stream_ops=ddp._CudaStreamOps(dev))
+        assert gb._hooks and len(gb.buckets) > 3
+        main_key = torch.cuda.current_stream(dev).cuda_stream
+        p0 = opt.fp.flat.clone()
+        for it in range(2):                       # second pass: events and buckets are re-used
+            opt.zero_grad()
+            loss = m.loss(batch)
+            loss.backward()
+            launched_early = sum(gb.launched)
+            gb.finish()
+            log = gb.last_wait_log
+            assert sorted(b for b, _ in log) == list(range(len(gb.buckets)))
+            streams = set(k for _, w in log for k in w)
+            assert len(streams) == 3 and main_key in streams, (streams, main_key)
+            assert any(len(w) > 1 for _, w in log)
+            assert launched_early >= 1, "no bucket was launched from the hooks while backward ran"
+            torch.cuda.synchronize()
+            got = opt.fp.grad.clone()
+            scale = want.abs().max().item()
+            err = (got - want).abs().max().item()
+            assert err <= 2e-4 * scale, (it, err, scale)   # split-K atomics reorder sums between two backwards
+        opt.step()
+        torch.cuda.synchronize()
+        assert not torch.equal(opt.fp.flat, p0)
+        gb.remove()
+        q.put(("ok", ddp.rccl_ranks(), len(gb.buckets), float(loss.item())))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put(("fail", traceback.format_exc(), 0, 0.0))
+        raise
+
+
+def test_one_rank_rccl_through_the_bucket_path(dev):
+    """The first RCCL communicator this code meets must not be the 8-GPU run: one rank, backend "nccl"
+    (= RCCL), GradBuckets forced onto the exchange-stream path with the three encoder streams on — async
+    all-reduce handles under ProcessGroupNCCL semantics, stream-side waits, averaging by 1/1.  Runs in a
+    child process (a process group is process-wide state)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, a, nb, loss = q.get(timeout=300)
+    p.join(timeout=120)
+    assert status == "ok", a
+    assert a == 1 and nb > 3 and np.isfinite(loss)
+    assert p.exitcode == 0

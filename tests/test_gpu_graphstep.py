@@ -251,3 +251,60 @@ def test_linear_fused_dropout_equals_product_then_dropout(dev, mode, act, with_r
     assert 0.25 < frac < (0.75 if act == "relu" else 0.35), frac        # ~30 % dropped (+ ReLU zeros)
     for a, b_ in zip(res[True][1], res[False][1]):
         assert _rel(a, b_) <= 2e-6
+
+
+def test_kept_loss_of_branch_streams_model_is_refused_before_the_capture(dev, monkeypatch):
+    """Round-2 fault (hipStreamEndCapture segfault): a `loss` kept from an eager step of the BRANCH-STREAMS model
+    keeps that step's AccumulateGrad nodes alive on their old streams.  The guard must refuse BEFORE the runtime
+    is entered, and must not depend on autograd's stream-mismatch warning, which the fused model silences
+    process-wide (models/applecider.py `_streams`).  The capture itself is replaced: a guard that misses fails
+    the assertion below instead of reaching the HIP runtime."""
+    from applecider_amd.graphstep import GraphedTrainStep, stale_autograd_parameters
+    m, batches = _fused(dev)
+    assert m.branch_streams
+    kept = m.train_step(batches[0])["loss"]          # eager step on three streams; the loss stays referenced
+    torch.cuda.synchronize()
+    assert getattr(m, "_branch_streams", None) is not None, "the model did not fork its encoder streams"
+    assert stale_autograd_parameters(list(m.parameters()))
+
+    def no_capture(self):
+        raise AssertionError("the stale-graph guard let the capture start")
+    monkeypatch.setattr(GraphedTrainStep, "_record", no_capture)
+    with pytest.raises(RuntimeError, match="earlier eager step is still alive"):
+        GraphedTrainStep(m, batches[0], step_fn=_step_fn)
+    del kept
+    assert not stale_autograd_parameters(list(m.parameters()))
+    monkeypatch.undo()
+    step = GraphedTrainStep(m, batches[0], step_fn=_step_fn)      # with the loss dropped the capture goes through
+    assert torch.isfinite(step(batches[1])).item()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_eager_forward_between_replays_sees_the_replayed_weights(dev, mode):
+    """A replay updates the parameters through raw pointers (no `_version` bump): the host-side weight copies
+    (bf16x3: (hi, lo) conv planes in the step cache; bf16: 16-bit mirrors) must be invalidated by the replay, or
+    validation after a graphed epoch runs on the weights of its first call (round-2 advisor finding)."""
+    from applecider_amd import hipops as H
+    from applecider_amd.graphstep import GraphedTrainStep
+    from applecider_amd.models.applecider import AppleCider
+    H.set_math(mode)
+    m, batches = _fused(dev)
+    step = GraphedTrainStep(m, batches[0], step_fn=_step_fn)
+    fwd = batches[2][:5]
+
+    def evaluate(model):
+        model.eval()
+        with torch.no_grad():
+            out = model(*fwd).clone()
+        model.train()
+        return out
+    step(batches[0])
+    first = evaluate(m)                      # fills the weight-copy caches
+    step(batches[1])
+    step(batches[0])
+    second = evaluate(m)
+    fresh = AppleCider(dict(CFG)).to(dev)
+    fresh.load_state_dict(m.state_dict())
+    want = evaluate(fresh)
+    assert _rel(second, want) <= 1e-6, "eager forward after replays used stale weight copies"
+    assert _rel(first, want) > 1e-5          # the two replays in between did move the logits

@@ -10,11 +10,26 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from common import SMALL_SPECTRA, T, assert_close, cfg_default, closed_form_sd, compact, gold, grads_by_ref_name
+from common import (SMALL_SPECTRA, T, assert_close, cfg_default, closed_form_sd, compact, gold, grads_by_ref_name,
+                    set_context)
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 GRAD_TOL = 2e-3
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def gmode(request):
+    """The golden model tests run in BOTH qualified arithmetic modes: exact fp32 matrix cores and the
+    benchmarked split bf16.  Bounds are the same unless a call states `x3=`; every
+    measured error lands in gpurun_out/parity_golden_modes.json."""
+    from applecider_amd import hipops as H
+    H.set_math(request.param)
+    name = request.node.name.replace(request.param, "").replace("[-", "[").replace("-]", "]").replace("[]", "")
+    set_context(name, request.param)
+    yield request.param
+    set_context(None, None)
+    H.set_math("f32")
 
 
 def build(cls, cfg, dev, salt=0):
@@ -44,7 +59,7 @@ def test_residual_tower_golden(dev, tag, dims):
     assert_close(gw[1], g[f"{tag}.dw_act"], GRAD_TOL, "dw activation.2")
 
 
-def test_astrominn_golden(dev):
+def test_astrominn_golden(dev, gmode):
     from applecider_amd.models.astrominn import AstroMiNN
     from applecider_amd.synthetic import make_batch
     g = gold("g3_astrominn.npz")
@@ -93,7 +108,7 @@ def test_astrominn_probabilities_and_training_mode(dev):
     assert all(np.isfinite(out))
 
 
-def test_spectranet_golden(dev):
+def test_spectranet_golden(dev, gmode):
     from applecider_amd.models.spectranet import SpectraNet
     from applecider_amd.synthetic import make_batch
     g = gold("g4_spectranet.npz")
@@ -129,7 +144,7 @@ def test_spectranet_golden(dev):
     assert_close(norms, g["full.gradnorm_all"], GRAD_TOL, "full grad norms")
 
 
-def test_spectranet_train_step_golden(dev):
+def test_spectranet_train_step_golden(dev, gmode):
     """C3 (spectranet.py:172-184): train_step under the injected SGD(0.01, 0.9) + CrossEntropyLoss with
     the int16 labels the reference's to_tensor emits, two steps (momentum buffer), against the
     reference's own run (golden g10)."""
@@ -193,7 +208,7 @@ def test_spectranet_batchnorm_golden(dev):
 
 
 @pytest.mark.parametrize("L", [128, 257])
-def test_baselinecls_golden(dev, L):
+def test_baselinecls_golden(dev, L, gmode):
     from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS
     from applecider_amd.synthetic import make_batch
     g = gold("g5_baselinecls.npz")
@@ -369,7 +384,7 @@ def _mpt_inputs():
     return data, pad
 
 
-def test_mpt_train_step_golden(dev):
+def test_mpt_train_step_golden(dev, gmode):
     """MPTModel.train_step against the reference's own step (g9: dropout 0, its random selection
     replaced by a fixed mask): loss, gradients before clipping, parameters after clip + AdamW."""
     from applecider_amd.models.HyraxBaselineCLS import MPTModel

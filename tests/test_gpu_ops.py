@@ -882,3 +882,35 @@ def test_conv_bank_bf16_cat_buffer(dev, bf16_mode, B, L, Cin, Cout, ks):
                       for w, bb, k in zip(ws, bs, ks)], 1).permute(0, 2, 1)
     ref = F.gelu(F.layer_norm(ycat, (3 * Cout,), gam, bet, 1e-5))
     close(a[0], ref, tol=2e-2, name="forward vs torch")
+
+
+def test_batchnorm_large_mean_many_rows_vs_torch(dev):
+    """Round-2 advisor finding: one-pass E[x^2] - mean^2 in fp32 cancels when |mean| >> std at the benchmark's row
+    counts.  Columns with means up to 1e3 and std 0.1 .. 1 over 2^20 rows (B*L of a SpectraNet stage), forward
+    statistics, output, running statistics and all gradients against F.batch_norm in fp64."""
+    import torch.nn.functional as F
+    from applecider_amd import hipops as H
+    rows, Cn = 1 << 20, 64
+    g = torch.Generator().manual_seed(3)
+    mean = torch.linspace(-1000.0, 1000.0, Cn)
+    std = torch.linspace(0.1, 1.0, Cn)
+    x = (torch.randn(rows, Cn, generator=g) * std + mean).to(dev).requires_grad_()
+    gamma = (1.0 + 0.1 * torch.randn(Cn, generator=g)).to(dev).requires_grad_()
+    beta = (0.1 * torch.randn(Cn, generator=g)).to(dev).requires_grad_()
+    rm, rv = torch.zeros(Cn, device=dev), torch.ones(Cn, device=dev)
+    go = torch.randn(rows, Cn, generator=g).to(dev)
+    y = H.batchnorm_act(x, gamma, beta, rm, rv, True, eps=1e-5, momentum=0.1, act=None)
+    y.backward(go)
+    x64 = x.detach().double().cpu().requires_grad_()
+    g64, b64 = gamma.detach().double().cpu().requires_grad_(), beta.detach().double().cpu().requires_grad_()
+    rm64, rv64 = torch.zeros(Cn, dtype=torch.float64), torch.ones(Cn, dtype=torch.float64)
+    y64 = F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    y64.backward(go.double().cpu())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    # the input itself carries |mean| / std * 2^-24 of rounding (up to 6e-4 of a standard deviation here)
+    assert rel(rv, rv64) <= 1e-4, rel(rv, rv64)
+    assert rel(rm, rm64) <= 1e-6
+    assert rel(y, y64.detach()) <= 1e-3      # x*scale + shift at |x*scale| ~ 1e4: 2^-24 of that per element
+    assert rel(x.grad, x64.grad) <= 2e-3
+    assert rel(gamma.grad, g64.grad) <= 1e-3
+    assert rel(beta.grad, b64.grad) <= 1e-4
