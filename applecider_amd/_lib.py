@@ -118,6 +118,8 @@ SIGNATURES = {
     "ac_stem_patchify": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_dwconv7x7_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_dwconv7x7_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_dwconv7x7_fwd_v": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "ac_dwconv7x7_bwd_v": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_avgpool_fwd": [_P, _P, _I32, _I32, _I32, _P],
     "ac_avgpool_bwd": [_P, _P, _I32, _I32, _I32, _P],
     "ac_maxpool4_fwd": [_P, _P, _I64, _P, _I32, _I32, _I32, _P],

@@ -438,6 +438,273 @@ __global__ __launch_bounds__(256) void dwconv_rows_bwd_kernel(const float *__res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined whole-row kernels (round 3).  The kernels above are load -> barrier -> compute -> store per
+// workgroup with ~1.2 waves of workgroups on the chip: every CU's loads, FMAs and stores happen one after
+// the other, so the launch runs at load + compute + store time (0.40 of HBM forward, 0.18 backward) although
+// each phase alone is faster than the HBM stream.  Here a PERSISTENT workgroup walks several (sample,
+// 32-channel slice) items with TWO plane buffers in LDS: the next item's plane arrives by LDS-DMA
+// (global_load_lds_dwordx4: 8 lanes = the 128-byte line of one pixel's 32 channels, one wave-instruction =
+// 8 pixels = 1 KiB, no VGPR round trip) while this item's rows are convolved and stored.  The DMA is waited
+// for with a COUNTED vmcnt (this item's output stores, issued later, stay in flight) and a raw s_barrier —
+// __syncthreads() would drain everything (cdna_hip_programming.md, "Pipelining across barriers").
+// The channel slice of a workgroup is fixed, so its 49 taps are loaded once.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+template <int W>
+struct PipeGeo {
+    static constexpr int HW = W * W;
+    static constexpr int NI = (HW + 7) / 8;          // DMA wave-instructions per plane (8 pixels each)
+    static constexpr int PLANE = NI * 8 * CG;        // floats per plane buffer (pixels padded to 8)
+};
+
+// wave `wv` of `nw` issues instructions wv, wv + nw, ... of one plane.  A RUNTIME loop with running addresses on
+// purpose: unrolled, hipcc hoists the 29 lane-constant 64-bit pixel offsets out of the item loop, spills them, and
+// every reload's vmcnt(0) drains the queue in front of each DMA (cdna_hip_programming.md, Appendix B pitfalls).
+template <int W>
+__device__ __forceinline__ void dma_plane(float *buf, const float *src, int C, int wv, int nw) {
+    constexpr int HW = W * W, NI = PipeGeo<W>::NI;
+    const int lane = threadIdx.x & 63;
+    const int pl = lane >> 3, ch = (lane & 7) * 4;
+    const float *sp = src + ch;
+#pragma unroll 1
+    for (int j = wv; j < NI; j += nw) {
+        int p = 8 * j + pl;
+        p = p < HW ? p : HW - 1;     // the pad pixels of the last instruction re-read the last pixel (never used)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid *)(sp + (unsigned)(p * C)), (lds_void *)(buf + 8 * j * CG), 16, 0, 0);
+    }
+}
+
+// SLOTS row slots per workgroup (threads = 32 channels x SLOTS), ROUNDS = rows per slot
+template <int W, int SLOTS>
+__global__ __launch_bounds__(32 * SLOTS, 2) void dwconv_pipe_fwd_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ w,
+                                                                      const float *__restrict__ bias,
+                                                                      float *__restrict__ y, int B, int C, int ncg) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    constexpr int HW = W * W, PL = PipeGeo<W>::PLANE, NWV = SLOTS / 2, ROUNDS = (W + SLOTS - 1) / SLOTS;
+    constexpr int NI = PipeGeo<W>::NI;
+    const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // item = (sample, slice): the slice of a workgroup is fixed (gridDim.x is a multiple of ncg)
+    const int cg = blockIdx.x % ncg, b0 = blockIdx.x / ncg, bstep = gridDim.x / ncg;
+    const int cglob = cg * CG + c;
+    float wt[49];
+    {
+        const float *wp = w + cglob;
+#pragma unroll
+        for (int k = 0; k < 49; ++k) {
+            wt[k] = *wp;
+            wp += C;
+        }
+    }
+    const float bv = bias ? bias[cglob] : 0.f;
+    if (b0 >= B) return;
+    dma_plane<W>(plane, x + (int64_t)b0 * HW * C + cg * CG, C, wv, NWV);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int b = b0; b < B; b += bstep) {
+        const bool more = b + bstep < B;
+        if (more) dma_plane<W>(plane + (cur ^ 1) * PL, x + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
+        const float *pb = plane + cur * PL + c;
+        float *yb = y + (int64_t)b * HW * C + cglob;
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int py_ = ps + SLOTS * r;
+            const bool rv = py_ < W;
+            const int py = rv ? py_ : W - 1;
+            float out[W];
+#pragma unroll
+            for (int o = 0; o < W; ++o) out[o] = bv;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = py + ky - 3;
+                if (yy >= 0 && yy < W) {
+                    float in[W];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) in[j] = pb[(yy * W + j) * CG];
+                    row_taps<W, false>(in, wt, ky, out);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float *yp = yb + (int64_t)py * W * C;
+            // W store instructions per round in EVERY wave — the count the vmcnt below relies on.  A slot without a
+            // row of its own (W % SLOTS != 0) recomputes the last row and stores the same values to the same
+            // addresses as that row's owner: no predicate, no branch around a store.
+            (void)rv;
+#pragma unroll
+            for (int o = 0; o < W; ++o) {
+                *yp = out[o];
+                yp += C;
+            }
+        }
+        if (more) {
+            // all but the youngest ROUNDS * W vector-memory operations (this item's stores) are done: the DMA of
+            // the next plane, issued before them, has landed
+            static_assert(ROUNDS * W <= 63, "vmcnt field");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS * W) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        cur ^= 1;
+    }
+}
+
+template <int W, int SLOTS>
+int launch_pipe_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C, hipStream_t stream) {
+    const int ncg = C / CG;
+    const size_t lds = (size_t)2 * PipeGeo<W>::PLANE * sizeof(float);
+    const int per_cu = (int)((160 * 1024) / lds) < (2048 / (32 * SLOTS)) ? (int)((160 * 1024) / lds) : (2048 / (32 * SLOTS));
+    int wgs = 256 * (per_cu < 1 ? 1 : per_cu);
+    wgs -= wgs % ncg;
+    if (wgs > B * ncg) wgs = B * ncg;
+    static bool configured = false;
+    if (!configured && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_fwd_kernel<W, SLOTS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
+    }
+    hipLaunchKernelGGL((dwconv_pipe_fwd_kernel<W, SLOTS>), dim3(wgs), dim3(32 * SLOTS), lds, stream, x, w, bias, y, B, C, ncg);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+// Backward, pipelined the same way: (dy, x) plane pairs double-buffered (4 buffers), one output row per thread
+// (SLOTS >= W), the 49 + 1 parameter-gradient sums of the thread's channel in registers over all items of the
+// workgroup (its channel slice is fixed), reduced over the row slots through LDS once at the end.
+template <int W, int SLOTS>
+__global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bwd_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ dx,
+    float *__restrict__ dw, float *__restrict__ dbias, int B, int C, int ncg) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    static_assert(SLOTS >= W, "one row per thread");
+    constexpr int HW = W * W, PL = PipeGeo<W>::PLANE, NWV = SLOTS / 2;
+    const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = blockIdx.x % ncg, b0 = blockIdx.x / ncg, bstep = gridDim.x / ncg;
+    const int cglob = cg * CG + c;
+    const bool rv = ps < W;
+    const int py = rv ? ps : W - 1;
+    float wt[49], dwacc[49];
+    float dbacc = 0.f;
+    {
+        const float *wp = w + cglob;
+#pragma unroll
+        for (int k = 0; k < 49; ++k) {
+            wt[k] = *wp;
+            wp += C;
+            dwacc[k] = 0.f;
+        }
+    }
+    if (b0 < B) {
+        dma_plane<W>(plane, dy + (int64_t)b0 * HW * C + cg * CG, C, wv, NWV);
+        dma_plane<W>(plane + PL, x + (int64_t)b0 * HW * C + cg * CG, C, wv, NWV);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int b = b0; b < B; b += bstep) {
+        const bool more = b + bstep < B;
+        if (more) {
+            float *nb = plane + (cur ^ 1) * 2 * PL;
+            dma_plane<W>(nb, dy + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
+            dma_plane<W>(nb + PL, x + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
+        }
+        const float *pdy = plane + cur * 2 * PL + c, *px = pdy + PL;
+        float out[W], d[W];
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            out[o] = 0.f;
+            // a slot without a row of its own recomputes the last row for dx (identical duplicate stores) and
+            // must add nothing to the parameter gradients
+            d[o] = rv ? pdy[(py * W + o) * CG] : 0.f;
+            dbacc += d[o];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = py + ky - 3;
+            if (yy >= 0 && yy < W) {
+                float in[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) in[j] = pdy[(yy * W + j) * CG];
+                row_taps<W, true>(in, wt, ky, out);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < W; ++j) in[j] = px[(yy * W + j) * CG];
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    float a = dwacc[ky * 7 + kx];
+#pragma unroll
+                    for (int o = 0; o < W; ++o)
+                        if (o + kx - 3 >= 0 && o + kx - 3 < W) a = fmaf(d[o], in[o + kx - 3], a);
+                    dwacc[ky * 7 + kx] = a;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float *dxp = dx + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            *dxp = out[o];
+            dxp += C;
+        }
+        if (more) {
+            static_assert(W <= 63, "vmcnt field");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        cur ^= 1;
+    }
+    // reduce the row slots through LDS (the plane buffers are idle now), one atomic per (tap, channel)
+    __syncthreads();
+    float *red = plane;  // [SLOTS][50][32]
+#pragma unroll
+    for (int k = 0; k < 49; ++k) red[(ps * 50 + k) * CG + c] = dwacc[k];
+    red[(ps * 50 + 49) * CG + c] = dbacc;
+    __syncthreads();
+    for (int k = ps; k < 50; k += SLOTS) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) sum += red[(q * 50 + k) * CG + c];
+        if (k < 49)
+            atomicAdd(&dw[k * C + cglob], sum);
+        else if (dbias)
+            atomicAdd(&dbias[cglob], sum);
+    }
+}
+
+template <int W, int SLOTS>
+int launch_pipe_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias, int B, int C,
+                    hipStream_t stream) {
+    const int ncg = C / CG;
+    const size_t planes = (size_t)4 * PipeGeo<W>::PLANE * sizeof(float), red = (size_t)SLOTS * 50 * CG * sizeof(float);
+    const size_t lds = planes > red ? planes : red;
+    if (lds > 160 * 1024) return AC_EINVAL;
+    int per_cu = (int)((160 * 1024) / lds);
+    const int by_threads = 2048 / (32 * SLOTS), by_regs = 512 / (32 * SLOTS) * 4;   // 2 waves per SIMD at ~200 registers
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu > by_regs) per_cu = by_regs;
+    if (per_cu < 1) per_cu = 1;
+    int wgs = 256 * per_cu;
+    wgs -= wgs % ncg;
+    if (wgs > B * ncg) wgs = B * ncg;
+    static bool configured = false;
+    if (!configured && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_bwd_kernel<W, SLOTS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
+    }
+    hipLaunchKernelGGL((dwconv_pipe_bwd_kernel<W, SLOTS>), dim3(wgs), dim3(32 * SLOTS), lds, stream, dy, x, w, dx, dw,
+                       dbias, B, C, ncg);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
 template <int W>
 int launch_rows_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C, hipStream_t stream) {
     const size_t lds = (size_t)W * W * CG * sizeof(float);
@@ -600,10 +867,13 @@ int launch_bwd(const float *dy, const float *x, const float *w, float *dx, float
 
 }  // namespace
 
-extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y,
-                                int32_t B, int32_t H, int32_t W, int32_t C, ac_stream_t stream_) {
+extern "C" int ac_dwconv7x7_fwd_v(const float *x, const float *w, const float *bias, float *y,
+                                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t variant, ac_stream_t stream_) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    // pipelined persistent kernels (variant 0 = automatic, 1 = the one-item-per-workgroup kernels below)
+    if (variant != 1 && H == W && (W == 15 || W == 7) && C % CG == 0 && ac_aligned16(x) && B * (C / CG) >= 256)
+        return W == 15 ? launch_pipe_fwd<15, 8>(x, w, bias, y, B, C, stream) : launch_pipe_fwd<7, 8>(x, w, bias, y, B, C, stream);
     if (H == W && (W == 1 || W == 3)) {
         const int spb = small_spb(B);
         dim3 grid((C + 63) / 64, (B + spb - 1) / spb);
@@ -624,11 +894,26 @@ extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bia
     return launch_fwd<5>(x, w, bias, y, B, H, W, C, stream);
 }
 
+extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y,
+                                int32_t B, int32_t H, int32_t W, int32_t C, ac_stream_t stream_) {
+    return ac_dwconv7x7_fwd_v(x, w, bias, y, B, H, W, C, 0, stream_);
+}
+
 extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w, float *dx,
                                 float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
                                 int32_t C, ac_stream_t stream_) {
+    return ac_dwconv7x7_bwd_v(dy, x, w, dx, dw, dbias, B, H, W, C, 0, stream_);
+}
+
+extern "C" int ac_dwconv7x7_bwd_v(const float *dy, const float *x, const float *w, float *dx,
+                                  float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
+                                  int32_t C, int32_t variant, ac_stream_t stream_) {
     if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
+    if (variant != 1 && H == W && (W == 15 || W == 7) && C % CG == 0 && ac_aligned16(x) && ac_aligned16(dy) &&
+        B * (C / CG) >= 256)
+        return W == 15 ? launch_pipe_bwd<15, 16>(dy, x, w, dx, dw, dbias, B, C, stream)
+                       : launch_pipe_bwd<7, 8>(dy, x, w, dx, dw, dbias, B, C, stream);
     if (H == W && (W == 1 || W == 3)) {
         const int spb = small_spb(B);
         dim3 grid((C + 63) / 64, (B + spb - 1) / spb);

@@ -286,6 +286,12 @@ int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bias, float *y
 int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
                      float *dbias, int32_t B, int32_t H, int32_t W, int32_t C,
                      ac_stream_t stream);
+/* The same two entry points with the kernel family selectable (A/B measurements, tests): variant 0 = automatic
+ * (what the plain entry points do), 1 = the one-item-per-workgroup kernels of round 2 (no LDS-DMA pipeline). */
+int ac_dwconv7x7_fwd_v(const float *x, const float *w, const float *bias, float *y, int32_t B, int32_t H,
+                       int32_t W, int32_t C, int32_t variant, ac_stream_t stream);
+int ac_dwconv7x7_bwd_v(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t variant, ac_stream_t stream);
 /* mean over the HW positions: [B, HW, C] -> [B, C]; bwd broadcasts dy/HW. */
 int ac_avgpool_fwd(const float *x, float *y, int32_t B, int32_t HW, int32_t C, ac_stream_t stream);
 int ac_avgpool_bwd(const float *dy, float *dx, int32_t B, int32_t HW, int32_t C,

@@ -79,7 +79,10 @@ def test_astrominn_golden(dev, gmode):
     gr = grads_by_ref_name(m)
     for k in g.files:
         if k.startswith("grad."):
-            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+            # split bf16: the 13 gradients measured 0.4e-3 .. 2.3e-3 on MI355X (profiles/r03_parity_golden_modes.json;
+            # exact-fp32 mode: <= 5e-5) — the logits differ by 1.8e-5 and CE's softmax - onehot is small against
+            # them at B = 32, so the whole backward inherits ~1e-3; stated bound 5e-3
+            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k, x3=5e-3)
     # one full train_step (zero_grad, fwd, CE, bwd, AdamW with the reference's 11 groups)
     m2 = build(AstroMiNN, cfg_default(), dev).eval()
     res = m2.train_step(batch)

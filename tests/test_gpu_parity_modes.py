@@ -171,8 +171,8 @@ def test_fused_b512_vs_cpu_oracle(dev, math_mode, fused_case):
 # softmax outputs (docs/pre_executed/testing/astrominn_example.ipynb cell 12: torch vs ONNX; `use_probabilities`
 # astrominn.py:297-298): the probabilities are held to F16_PROB_TOL below, the logits to the stated looser bound,
 # labels by the margin-aware rule.
-F16_PROB_TOL = 2e-3          # max |p_f16 - p_oracle| over samples whose MoE routing did not flip
-F16_MEDIAN_LOGIT_TOL = 2e-3  # median sample, relative to the largest logit
+F16_PROB_TOL = 5e-4          # max |p_f16 - p_oracle| over samples whose MoE routing did not flip (measured 9e-5)
+F16_MEDIAN_LOGIT_TOL = 1e-3  # median sample, relative to the largest logit (measured 3.1e-4; worst sample 2.1e-3)
 F16_OUTLIER_SHARE = 0.02     # share of samples allowed beyond 5e-2 (top-2 routing near-ties, as in bf16 mode)
 F16_LABEL_AGREEMENT = 0.98
 
