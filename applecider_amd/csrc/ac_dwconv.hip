@@ -573,23 +573,32 @@ int launch_pipe_fwd(const float *x, const float *w, const float *bias, float *y,
     return AC_OK;
 }
 
-// Backward, pipelined the same way: (dy, x) plane pairs double-buffered (4 buffers), one output row per thread
-// (SLOTS >= W), the 49 + 1 parameter-gradient sums of the thread's channel in registers over all items of the
-// workgroup (its channel slice is fixed), reduced over the row slots through LDS once at the end.
+// Backward, pipelined the same way: (dy, x) plane pairs double-buffered (4 buffers = 119 KB at 15 x 15: one
+// workgroup of 512 threads per CU).  Two thread maps per item, so that neither needs many registers:
+//   phase A  thread = (channel, output row): dx row = correlation of dy with the flipped taps (49 taps in registers);
+//            the centre row it reads is dy[row] itself -> its share of dbias
+//   phase B  thread = (channel, tap row ky, half of the rows): dw[ky][0..6] += sum over its rows of dy[row] x[row+ky-3]
+//            — SEVEN running sums per thread instead of the 49 a (channel, row) thread would carry over all items
+//            (that form needed 256 registers and spilled)
+// The sums stay in registers over all items of the workgroup (fixed channel slice) and meet in LDS once at the end.
 template <int W, int SLOTS>
 __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ dx,
     float *__restrict__ dw, float *__restrict__ dbias, int B, int C, int ncg) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
-    static_assert(SLOTS >= W, "one row per thread");
+    static_assert(SLOTS >= W && (SLOTS == 8 || SLOTS == 16), "one output row per thread; 8 tap-row slots per half");
     constexpr int HW = W * W, PL = PipeGeo<W>::PLANE, NWV = SLOTS / 2;
+    constexpr int HALVES = SLOTS / 8, RH = (W + HALVES - 1) / HALVES;   // rows per half in phase B
     const int c = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cg = blockIdx.x % ncg, b0 = blockIdx.x / ncg, bstep = gridDim.x / ncg;
     const int cglob = cg * CG + c;
-    const bool rv = ps < W;
+    const bool rv = ps < W;                  // phase A: the slot owns a row (else it repeats the last row's dx)
     const int py = rv ? ps : W - 1;
-    float wt[49], dwacc[49];
+    const int kyb = ps & 7, hb = ps >> 3;    // phase B: tap row, half
+    const bool bv = kyb < 7;
+    const int r_begin = hb * RH, r_end = (r_begin + RH) < W ? (r_begin + RH) : W;
+    float wt[49], dwacc[7];
     float dbacc = 0.f;
     {
         const float *wp = w + cglob;
@@ -597,8 +606,9 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
         for (int k = 0; k < 49; ++k) {
             wt[k] = *wp;
             wp += C;
-            dwacc[k] = 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) dwacc[k] = 0.f;
     }
     if (b0 < B) {
         dma_plane<W>(plane, dy + (int64_t)b0 * HW * C + cg * CG, C, wv, NWV);
@@ -615,42 +625,53 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
             dma_plane<W>(nb + PL, x + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
         }
         const float *pdy = plane + cur * 2 * PL + c, *px = pdy + PL;
-        float out[W], d[W];
+        // ---- phase A: dx row
+        {
+            float out[W];
 #pragma unroll
-        for (int o = 0; o < W; ++o) {
-            out[o] = 0.f;
-            // a slot without a row of its own recomputes the last row for dx (identical duplicate stores) and
-            // must add nothing to the parameter gradients
-            d[o] = rv ? pdy[(py * W + o) * CG] : 0.f;
-            dbacc += d[o];
-        }
+            for (int o = 0; o < W; ++o) out[o] = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const int yy = py + ky - 3;
-            if (yy >= 0 && yy < W) {
-                float in[W];
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = py + ky - 3;
+                if (yy >= 0 && yy < W) {
+                    float in[W];
 #pragma unroll
-                for (int j = 0; j < W; ++j) in[j] = pdy[(yy * W + j) * CG];
-                row_taps<W, true>(in, wt, ky, out);
+                    for (int j = 0; j < W; ++j) in[j] = pdy[(yy * W + j) * CG];
+                    if (ky == 3 && rv) {
+#pragma unroll
+                        for (int j = 0; j < W; ++j) dbacc += in[j];
+                    }
+                    row_taps<W, true>(in, wt, ky, out);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            float *dxp = dx + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
+#pragma unroll
+            for (int o = 0; o < W; ++o) {   // W stores in every wave (a slot without a row repeats the last row)
+                *dxp = out[o];
+                dxp += C;
+            }
+        }
+        // ---- phase B: dw[ky][:] over this half's rows
+        if (bv) {
+#pragma unroll 1
+            for (int r = r_begin; r < r_end; ++r) {
+                const int yy = r + kyb - 3;
+                if (yy < 0 || yy >= W) continue;
+                float d[W], in[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) d[j] = pdy[(r * W + j) * CG];
 #pragma unroll
                 for (int j = 0; j < W; ++j) in[j] = px[(yy * W + j) * CG];
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
-                    float a = dwacc[ky * 7 + kx];
+                    float a = dwacc[kx];
 #pragma unroll
                     for (int o = 0; o < W; ++o)
                         if (o + kx - 3 >= 0 && o + kx - 3 < W) a = fmaf(d[o], in[o + kx - 3], a);
-                    dwacc[ky * 7 + kx] = a;
+                    dwacc[kx] = a;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float *dxp = dx + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
-#pragma unroll
-        for (int o = 0; o < W; ++o) {
-            *dxp = out[o];
-            dxp += C;
         }
         if (more) {
             static_assert(W <= 63, "vmcnt field");
@@ -659,21 +680,26 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
         }
         cur ^= 1;
     }
-    // reduce the row slots through LDS (the plane buffers are idle now), one atomic per (tap, channel)
+    // the halves' tap-row sums and the row slots' dbias shares meet in LDS (the plane buffers are idle now)
     __syncthreads();
-    float *red = plane;  // [SLOTS][50][32]
+    float *red = plane;   // [SLOTS][8][32]: 7 tap sums (phase B) + the slot's dbias share (phase A)
 #pragma unroll
-    for (int k = 0; k < 49; ++k) red[(ps * 50 + k) * CG + c] = dwacc[k];
-    red[(ps * 50 + 49) * CG + c] = dbacc;
+    for (int k = 0; k < 7; ++k) red[(ps * 8 + k) * CG + c] = bv ? dwacc[k] : 0.f;
+    red[(ps * 8 + 7) * CG + c] = dbacc;
     __syncthreads();
-    for (int k = ps; k < 50; k += SLOTS) {
+    if (ps < 7) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            float sum = 0.f;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) sum += red[((h * 8 + ps) * 8 + kx) * CG + c];
+            atomicAdd(&dw[(ps * 7 + kx) * C + cglob], sum);
+        }
+    } else if (ps == 7 && dbias) {
         float sum = 0.f;
 #pragma unroll
-        for (int q = 0; q < SLOTS; ++q) sum += red[(q * 50 + k) * CG + c];
-        if (k < 49)
-            atomicAdd(&dw[k * C + cglob], sum);
-        else if (dbias)
-            atomicAdd(&dbias[cglob], sum);
+        for (int q = 0; q < SLOTS; ++q) sum += red[(q * 8 + 7) * CG + c];
+        atomicAdd(&dbias[cglob], sum);
     }
 }
 
@@ -681,11 +707,11 @@ template <int W, int SLOTS>
 int launch_pipe_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias, int B, int C,
                     hipStream_t stream) {
     const int ncg = C / CG;
-    const size_t planes = (size_t)4 * PipeGeo<W>::PLANE * sizeof(float), red = (size_t)SLOTS * 50 * CG * sizeof(float);
+    const size_t planes = (size_t)4 * PipeGeo<W>::PLANE * sizeof(float), red = (size_t)SLOTS * 8 * CG * sizeof(float);
     const size_t lds = planes > red ? planes : red;
     if (lds > 160 * 1024) return AC_EINVAL;
     int per_cu = (int)((160 * 1024) / lds);
-    const int by_threads = 2048 / (32 * SLOTS), by_regs = 512 / (32 * SLOTS) * 4;   // 2 waves per SIMD at ~200 registers
+    const int by_threads = 2048 / (32 * SLOTS), by_regs = 512 / (32 * SLOTS);    // 2 waves per SIMD (the kernels take ~200-256 registers)
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;

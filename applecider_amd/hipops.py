@@ -1346,6 +1346,9 @@ def stem_patchify(img: torch.Tensor):
     return patches, OH, OW
 
 
+_DWCONV_VARIANT = 0   # 0: automatic (pipelined LDS-DMA kernels where they apply); 1: the round-2 kernels (A/B, tests)
+
+
 class _DWConv7(Function):
     """x [B,H,W,C] NHWC, w [49,C], b [C]."""
 
@@ -1354,8 +1357,12 @@ class _DWConv7(Function):
         x, w = _chk(x, "x"), _chk(w, "w")
         B, H, W_, Cn = x.shape
         y = torch.empty_like(x)
-        _lib.check(_lib_().ac_dwconv7x7_fwd(_p(x), _p(w), _p(b), _p(y), B, H, W_, Cn, _stream()),
-                   "ac_dwconv7x7_fwd")
+        if _DWCONV_VARIANT:
+            _lib.check(_lib_().ac_dwconv7x7_fwd_v(_p(x), _p(w), _p(b), _p(y), B, H, W_, Cn, _DWCONV_VARIANT, _stream()),
+                       "ac_dwconv7x7_fwd_v")
+        else:
+            _lib.check(_lib_().ac_dwconv7x7_fwd(_p(x), _p(w), _p(b), _p(y), B, H, W_, Cn, _stream()),
+                       "ac_dwconv7x7_fwd")
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         ctx.wp, ctx.bp = w, b
@@ -1371,8 +1378,12 @@ class _DWConv7(Function):
         both = ws is not None and (bs is not None or not ctx.has_b)
         dw = ws if both else torch.zeros_like(w)
         db = bs if (both and ctx.has_b) else torch.zeros(Cn, device=x.device, dtype=torch.float32)
-        _lib.check(_lib_().ac_dwconv7x7_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
-                                            Cn, _stream()), "ac_dwconv7x7_bwd")
+        if _DWCONV_VARIANT:
+            _lib.check(_lib_().ac_dwconv7x7_bwd_v(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
+                                                  Cn, _DWCONV_VARIANT, _stream()), "ac_dwconv7x7_bwd_v")
+        else:
+            _lib.check(_lib_().ac_dwconv7x7_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
+                                                Cn, _stream()), "ac_dwconv7x7_bwd")
         if both:
             _grad_written(ctx.wp)
             if ctx.has_b:

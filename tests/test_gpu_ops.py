@@ -208,6 +208,40 @@ def test_dwconv(dev, B, H_, C):
     close(bd.grad, b.grad, name="db")
 
 
+@pytest.mark.parametrize("B,H_,C", [(171, 15, 96), (513, 15, 96), (86, 15, 96), (128, 7, 192), (343, 7, 192), (700, 15, 32)])
+def test_dwconv_pipelined_kernels(dev, B, H_, C):
+    """The persistent LDS-DMA kernels (several (sample, slice) items per workgroup, double-buffered planes, counted
+    vmcnt): batches that give workgroups unequal item counts, a single item, and more items than the grid — against
+    torch's grouped conv2d (what timm's block dispatches to, astrominn.py:12-17) and bit-for-bit (forward, dx)
+    against the one-item-per-workgroup kernels."""
+    from applecider_amd import hipops as H
+    assert B * (C // 32) >= 256, "shape would not take the pipelined path"
+    x = g(dev, B, C, H_, H_, seed=1).requires_grad_()
+    w = (g(dev, C, 1, 7, 7, seed=2) / 7).requires_grad_()
+    b = g(dev, C, seed=3).requires_grad_()
+    y = F.conv2d(x, w, b, padding=3, groups=C)
+    go = g(dev, *y.shape, seed=4)
+    y.backward(go)
+    res = {}
+    for variant in (0, 1):
+        H._DWCONV_VARIANT = variant
+        try:
+            xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_()
+            wd = w.detach().reshape(C, 49).t().contiguous().to(dev).requires_grad_()
+            bd = b.detach().to(dev).requires_grad_()
+            yd = H.dwconv7x7(xd, wd, bd)
+            yd.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+            torch.cuda.synchronize()
+        finally:
+            H._DWCONV_VARIANT = 0
+        close(yd.permute(0, 3, 1, 2), y, name=f"y v{variant}")
+        close(xd.grad.permute(0, 3, 1, 2), x.grad, name=f"dx v{variant}")
+        close(wd.grad.t().reshape(C, 1, 7, 7), w.grad, name=f"dw v{variant}")
+        close(bd.grad, b.grad, name=f"db v{variant}")
+        res[variant] = (yd.detach(), xd.grad)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("B,H_,C,Co", [(4, 15, 96, 192), (4, 7, 192, 384), (8, 3, 384, 768), (3, 8, 32, 64)])
 def test_patch_conv2x2(dev, B, H_, C, Co):
     from applecider_amd import hipops as H

@@ -7,6 +7,9 @@ from applecider_amd import hipops as H
 
 dev = torch.device("cuda")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+H._DWCONV_VARIANT = VAR
+print(f"variant {VAR} (0 = pipelined LDS-DMA kernels, 1 = round-2 kernels)")
 for (S, C) in ((15, 96), (7, 192), (3, 384)):
     x = torch.randn(B, S, S, C, device=dev, requires_grad=True)
     w = torch.randn(49, C, device=dev, requires_grad=True)
