@@ -805,6 +805,235 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the same product with the weight stream on a RING of four half-stages filled by LDS-DMA.
+// Counters on the kernel above (profiles/r03_pmc_conv_counters.json): matrix pipe busy 0.59-0.64 of the cycles,
+// every wave parked 0.28 of its time at s_waitcnt / s_barrier, 23 % of the LDS cycles bank conflicts.  Its K tile
+// (one tap x 64 channels, 96 MFMAs per wave) ends in a barrier behind which all eight waves start the next tile by
+// reading 16 fragments each before their first MFMA — the two waves of a SIMD in lock-step, so nothing covers it
+// (~600 of ~3 100 cycles per tile) — and the weights travel global -> VGPR -> ds_write_b128.
+// Here:
+//   * a stage holds HALF a K tile (32 channels x BN rows x (hi, lo) = 16 KB at BN = 128) and the ring has four:
+//     half j + 3 is fetched by LDS-DMA (two wave-instructions per wave, no VGPRs, no ds_write) while half j is
+//     multiplied; `s_waitcnt vmcnt(2)` + a raw s_barrier per half publish half j + 2;
+//   * so the fragments of half j + 1 are visible one barrier EARLY and are read under the MFMAs of half j, across
+//     the barrier (A fragments come from the resident window and never depended on it): a wave leaves every barrier
+//     with 24 MFMAs of operands in registers — no read burst in front of the matrix pipe;
+//   * LDS images that are conflict-free for the 16x16x32 fragment shape: window rows (128 B) rotate their 16-byte
+//     chunks by 2 * (row >> 1) (any tap offset), weight rows (64 B) by 2 * (row >> 2); the DMA writes lane-linear,
+//     so the weight rotation is applied to each lane's SOURCE address (cdna_hip_programming.md rule 21).
+// Same tiles, chunking, two-group (N <= 64) form and epilogue as the kernel above; WM = 4 only.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int win_off16(int r, int cc) { return r * 64 + (((cc + (r & ~1)) & 7) << 3); }
+typedef __attribute__((address_space(3))) void cw_lds_void;
+typedef __attribute__((address_space(1))) const void cw_gbl_cvoid;
+
+template <int WM, int WN, int GR>
+__global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(ConvWinParams p, int TC) {
+    constexpr int GT = WM * WN * 64, NT = GR * GT, BM = WM * 64, BN = WN * 64, CC = 64;
+    constexpr int NWG = WM * WN;              // waves per group
+    constexpr int HP = BN * 32, HS = 2 * HP;  // half-stage plane / half-stage (hi | lo), elements
+    static_assert(WM == 4 && BN == 16 * NWG, "one 16-row DMA block per wave and plane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short *win_h = reinterpret_cast<unsigned short *>(smem);
+    const ac_convwin_desc &d = p.d;
+    const int Wrows = (d.L < BM ? (BM / d.L) * (d.L + TC - 1) : BM + TC - 1);
+    unsigned short *win_l = win_h + Wrows * CC;
+    const int t = threadIdx.x, lane = t & 63;
+    const int grp = (t >> 6) / NWG, wave = (t >> 6) % NWG;
+    unsigned short *ring = win_l + Wrows * CC + grp * 4 * HS;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, g = lane >> 4;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tn = wg % p.tiles_n;
+    const int R0 = (wg / p.tiles_n) * BM;
+    const int b = R0 / d.L, l0 = R0 - b * d.L;
+    const int Ls = d.L < BM ? d.L : BM, spt = BM / Ls;
+    const int lsh = 31 - __builtin_clz(Ls);
+
+    const unsigned short *aptr = (const unsigned short *)d.a + (int64_t)b * d.a_batch_stride +
+                                 (int64_t)(d.row_base + l0) * d.a_row_stride + d.a_col_off;
+    // DMA source of this lane: weight row 16 * wave + (lane >> 2), the chunk that belongs at position lane & 3
+    const unsigned short *wsrc;
+    {
+        int n = tn * BN + 16 * wave + (lane >> 2);
+        n = n < d.N ? n : d.N - 1;
+        const int chunk = ((lane & 3) - 2 * (lane >> 4)) & 3;
+        wsrc = (const unsigned short *)d.w + (int64_t)n * d.w_row_stride + 8 * chunk;
+    }
+    // fragment read offsets (elements): weight rows 16 j + lr of the wave's 64 columns, chunk g rotated
+    const int boff = (wn * 64 + lr) * 32 + (((g + 2 * (lr >> 2)) & 3) << 3);
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acs[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int cchunks = d.C / CC, csplit = gridDim.y;
+    const int cper = (cchunks + csplit - 1) / csplit;
+    const int c_begin = blockIdx.y * cper, c_end = (c_begin + cper) < cchunks ? (c_begin + cper) : cchunks;
+    for (int cch = c_begin; cch < c_end; ++cch) {
+        for (int t0 = 0; t0 < d.k; t0 += TC) {
+            const int tc = (d.k - t0) < TC ? (d.k - t0) : TC;
+            __syncthreads();   // previous chunk: window and ring idle, every DMA drained
+            const int wr = Ls + tc - 1;
+            {
+                const unsigned short *a = aptr + (int64_t)t0 * d.a_row_stride + cch * CC;
+                for (int idx = t; idx < spt * wr * 8; idx += NT) {
+                    const int rr_ = idx >> 3, cc = idx & 7;
+                    const int sidx = spt > 1 ? rr_ / wr : 0, r = rr_ - sidx * wr;
+                    const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
+                    *(u32x4 *)(win_h + win_off16(rr_, cc)) = ac_gload<u32x4>(src);
+                    *(u32x4 *)(win_l + win_off16(rr_, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
+                }
+            }
+            const int ntile = (tc + GR - 1) / GR, nhalf = 2 * ntile;
+            // half jj of this group's sequence: tile jj >> 1 (tap GR * tile + grp of the chunk, clamped: a tile past
+            // the chunk's last tap is fetched from the last tap and not multiplied), channels 32 * (jj & 1) ..
+            auto tapl = [&](int jj) { const int o = GR * (jj >> 1) + grp; return o < tc ? o : tc - 1; };
+            auto issue_dma = [&](int jslot, int jj) {
+                const int tap = t0 + tapl(jj);
+                const int64_t ko = (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + cch * CC + 32 * (jj & 1);
+                unsigned short *dst = ring + (jslot & 3) * HS + wave * 16 * 32;
+                __builtin_amdgcn_global_load_lds((cw_gbl_cvoid *)(wsrc + ko), (cw_lds_void *)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((cw_gbl_cvoid *)(wsrc + ko + d.w_lo_off), (cw_lds_void *)(dst + HP), 16, 0, 0);
+            };
+            int ar[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm * 64 + 16 * i + lr;
+                ar[i] = (m >> lsh) * wr + (m & (Ls - 1));
+            }
+            bf16x8 Bf[2][8], Af[2][2][4];   // [parity of the half][row half h][hi i0 i1 | lo i0 i1]
+            auto ldB = [&](int jj, bf16x8 (&Bv)[8]) {
+                const unsigned short *bt = ring + (jj & 3) * HS + boff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Bv[j] = *(const bf16x8 *)(bt + j * 16 * 32);
+                    Bv[4 + j] = *(const bf16x8 *)(bt + HP + j * 16 * 32);
+                }
+            };
+            auto ldA = [&](int jj, int h, bf16x8 (&A)[4]) {
+                const int to = tapl(jj), cc = 4 * (jj & 1) + g;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int o = win_off16(ar[2 * h + i] + to, cc);
+                    A[i] = *(const bf16x8 *)(win_h + o);
+                    A[2 + i] = *(const bf16x8 *)(win_l + o);
+                }
+            };
+            auto mm = [&](int h, const bf16x8 (&A)[4], const bf16x8 (&Bv)[8]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[2 + i], Bv[j], acs[2 * h + i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[i], Bv[4 + j], acs[2 * h + i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[i], Bv[j], acs[2 * h + i][j]);
+            };
+            const int lasth = nhalf - 1;
+            issue_dma(0, 0);
+            issue_dma(1, 1);
+            issue_dma(2, 2 < lasth ? 2 : lasth);
+            __syncthreads();   // window visible, halves 0 .. 2 landed (a __syncthreads waits for the DMA queue as well)
+            ldB(0, Bf[0]);
+            ldA(0, 0, Af[0][0]);
+            ldA(0, 1, Af[0][1]);
+            // one half: MFMAs of half j on its own register set; all 16 fragments of half j + 1 are read into the
+            // other set under them (two full A / B sets: 96 operand registers), so the wait in front of the next
+            // half's first MFMA is for reads that are 24 MFMAs old
+            auto half = [&](int j, const bf16x8 (&Bcur)[8], bf16x8 (&Bnext)[8], const bf16x8 (&Acur)[2][4],
+                            bf16x8 (&Anext)[2][4]) {
+                const int jn = j + 1 < lasth ? j + 1 : lasth;
+                const bool valid = GR == 1 || GR * (j >> 1) + grp < tc;
+                issue_dma(j + 3, j + 3 < lasth ? j + 3 : lasth);
+                __builtin_amdgcn_sched_barrier(0);
+                if (valid) mm(0, Acur[0], Bcur);
+                __builtin_amdgcn_sched_barrier(0);
+                ldB(jn, Bnext);
+                ldA(jn, 0, Anext[0]);
+                ldA(jn, 1, Anext[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (valid) mm(1, Acur[1], Bcur);
+                __builtin_amdgcn_sched_barrier(0);
+                // all but this half's two DMA instructions are done: half j + 2 has landed in every wave's share
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int j = 0; j < nhalf; j += 2) {
+                half(j, Bf[0], Bf[1], Af[0], Af[1]);
+                half(j + 1, Bf[1], Bf[0], Af[1], Af[0]);
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (GR == 2) {   // group 1 hands its accumulators to group 0 through the (idle) window
+        float *xch = smem + wave * 4096;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xch[((i * 4 + j) * 4 + e) * 64 + lane] = acs[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acs[i][j][e] += xch[((i * 4 + j) * 4 + e) * 64 + lane];
+    }
+    float *cb = d.c + (int64_t)R0 * d.ldc;
+    float *wbuf = smem + wave * (GR == 2 ? 4096 : 2048);
+    const int rsub = lane >> 4, c4 = 4 * (lane & 15);
+    const int n = tn * BN + wn * 64 + c4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias && n < d.N && blockIdx.y == 0) bias4 = *(const f32x4 *)(d.bias + n);
+#pragma unroll
+    for (int sa = 0; sa < 2; ++sa) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    wbuf[(16 * i + 4 * (lane >> 4) + e) * 64 + 16 * j + (lane & 15)] = acs[2 * sa + i][j][e];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + rsub;
+            f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
+            if (n < d.N) {
+                const int64_t row = wm * 64 + sa * 32 + r;
+                f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
+                if (csplit > 1) {
+                    float *df = (float *)dst;
+                    atomicAdd(df, v[0]);
+                    atomicAdd(df + 1, v[1]);
+                    atomicAdd(df + 2, v[2]);
+                    atomicAdd(df + 3, v[3]);
+                } else {
+                    if (d.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
 template <int WM, int WN, bool S16 = true, int GR = 1>
 int launch_x3(ConvWinParams &p, hipStream_t stream) {
     if (S16 && p.d.variant == 2) return launch_x3<WM, WN, false, 1>(p, stream);   // variant 2: the 32x32x16 form
@@ -846,6 +1075,47 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
         if (e != hipSuccess) return -(int)e - 2000;
     }
     hipLaunchKernelGGL((conv1d_window_x3_kernel<WM, WN, S16, GR>), dim3(wgs, csplit), dim3(NT), lds, stream, p, TC);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+template <int WM, int WN, int GR>
+int launch_x3r(ConvWinParams &p, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64, NT = GR * WM * WN * 64;
+    const ac_convwin_desc &d = p.d;
+    const size_t stages = (size_t)GR * 4 * 2 * BN * 32 * sizeof(short);   // ring of four half-stages per group
+    const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
+    const int spt = d.L < BM ? BM / d.L : 1, Ls = d.L < BM ? d.L : BM;
+    int TC = rows_budget / spt - Ls + 1;
+    if (TC < 1) return AC_EINVAL;
+    if (TC > d.k) TC = d.k;
+    const size_t lds = (size_t)spt * (Ls + TC - 1) * 64 * 2 * sizeof(short) + stages;
+    if (lds < (size_t)WM * WN * (GR == 2 ? 16384 : 8192)) return AC_EINVAL;
+    p.tiles_l = d.L / BM;
+    p.tiles_n = (d.N + BN - 1) / BN;
+    p.cchunks = 8;
+    p.vec_epi = 1;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3r_kernel<WM, WN, GR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
+    }
+    const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
+    int csplit = 1;
+    const int wgs = row_tiles * p.tiles_n, cchunks = d.C / 64;
+    if (wgs <= 128 && cchunks >= 4 && d.ldc == d.N) {
+        csplit = 256 / wgs;
+        if (csplit > cchunks / 2) csplit = cchunks / 2;
+        if (csplit > 4) csplit = 4;
+        if (csplit < 1) csplit = 1;
+    }
+    if (csplit > 1 && !d.accumulate) {
+        hipError_t e = hipMemsetAsync(d.c, 0, (size_t)d.B * d.L * d.ldc * sizeof(float), stream);
+        if (e != hipSuccess) return -(int)e - 2000;
+    }
+    hipLaunchKernelGGL((conv1d_window_x3r_kernel<WM, WN, GR>), dim3(wgs, csplit), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -892,6 +1162,9 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
     const bool wide = d.N > 64;
     // N <= 64: one column of waves only -> a second wave group on the odd taps (needs a few taps to share)
     const bool two = !wide && d.k >= 4;
+    // variant 5: the ring kernel (weights by LDS-DMA into four half-stages, fragments prefetched across the barrier)
+    if (d.variant == 5 && (d.L % 256 == 0 || short_seq) && (wide || two))
+        return wide ? launch_x3r<4, 2, 1>(p, stream) : launch_x3r<4, 1, 2>(p, stream);
     if (d.L % 256 == 0 || short_seq)
         return wide ? launch_x3<4, 2>(p, stream) : (two ? launch_x3<4, 1, true, 2>(p, stream) : launch_x3<4, 1>(p, stream));
     return wide ? launch_x3<2, 2>(p, stream) : (two ? launch_x3<2, 1, true, 2>(p, stream) : launch_x3<2, 1>(p, stream));

@@ -257,7 +257,7 @@ def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
 
 
 @pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "ring"])
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (2, 128, 128, 64, (3, 15, 61)),
                                              (1, 256, 256, 128, (7, 13, 31)), (2, 64, 128, 256, (3, 15, 61)),
                                              (8, 64, 128, 256, (3, 11, 31)), (32, 16, 512, 128, (3, 7, 13)),
@@ -281,12 +281,16 @@ def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
     xd = x.detach().float().permute(0, 2, 1).contiguous().to(dev).requires_grad_()
     wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
     bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
-    H._CONVWIN_X3_FUSED = fused
+    # "ring": the round-3 kernel (weights by LDS-DMA into a ring of half-stages, fragments prefetched across the
+    # barrier); shapes it does not cover fall through to the round-2 kernel inside the library
+    H._CONVWIN_X3_FUSED = bool(fused)
+    H._X3_VARIANT = 5 if fused == "ring" else 0
     try:
         yd = H.conv_group1d(xd, ks, wd, bd)
         yd.backward(go.float().permute(0, 2, 1).contiguous().to(dev))
     finally:
         H._CONVWIN_X3_FUSED = True
+        H._X3_VARIANT = 0
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
     tol = 5e-5
     assert rel(yd.permute(0, 2, 1), y.detach()) <= tol
