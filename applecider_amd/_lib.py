@@ -100,6 +100,8 @@ SIGNATURES = {
     "ac_layernorm_fwd": [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _F, _I32, _P, _I64, _I32, _P],
     "ac_layernorm_bwd": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
                          _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
+    "ac_layernorm_bwd_split": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32,
+                               _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_mpt_mask": [_P, _P, _P, _I32, _I32, C.c_double, C.c_uint64, _P, _P],
     "ac_mpt_loss_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _F, _F, _P],
     "ac_colsum": [_P, _I64, _P, _I64, _I32, _I32, _P],
@@ -108,6 +110,7 @@ SIGNATURES = {
     "ac_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "ac_act_fwd": [_P, _P, _I64, _I32, _P],
     "ac_copy2d": [_P, _I64, _P, _I64, _I64, _I32, _P],
+    "ac_scale_add_rows": [_P, _P, _P, _P, _I64, _I32, _P],
     "ac_gather_cols": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
     "ac_gate_fwd": [_P, _P, _P, _P, _I64, _P],
     "ac_gate_bwd": [_P, _P, _P, _P, _P, _I64, _P],

@@ -828,7 +828,9 @@ __device__ __forceinline__ int win_off16(int r, int cc) { return r * 64 + (((cc 
 typedef __attribute__((address_space(3))) void cw_lds_void;
 typedef __attribute__((address_space(1))) const void cw_gbl_cvoid;
 
-template <int WM, int WN, int GR>
+// SHORT: L < BM (whole samples per tile): window rows per row block by the general (sample, position) map; else
+// the wave's four row blocks are 16 rows apart and share one address (immediate offsets), ~6 VALU per half for A
+template <int WM, int WN, int GR, bool SHORT, int NS>
 __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(ConvWinParams p, int TC) {
     constexpr int GT = WM * WN * 64, NT = GR * GT, BM = WM * 64, BN = WN * 64, CC = 64;
     constexpr int NWG = WM * WN;              // waves per group
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
     unsigned short *win_l = win_h + Wrows * CC;
     const int t = threadIdx.x, lane = t & 63;
     const int grp = (t >> 6) / NWG, wave = (t >> 6) % NWG;
-    unsigned short *ring = win_l + Wrows * CC + grp * 4 * HS;
+    unsigned short *ring = win_l + Wrows * CC + grp * NS * HS;   // NS half-stages per group
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, g = lane >> 4;
 
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
             auto issue_dma = [&](int jslot, int jj) {
                 const int tap = t0 + tapl(jj);
                 const int64_t ko = (int64_t)(d.flip ? d.k - 1 - tap : tap) * d.w_tap_stride + cch * CC + 32 * (jj & 1);
-                unsigned short *dst = ring + (jslot & 3) * HS + wave * 16 * 32;
+                unsigned short *dst = ring + (jslot % NS) * HS + wave * 16 * 32;
                 __builtin_amdgcn_global_load_lds((cw_gbl_cvoid *)(wsrc + ko), (cw_lds_void *)dst, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((cw_gbl_cvoid *)(wsrc + ko + d.w_lo_off), (cw_lds_void *)(dst + HP), 16, 0, 0);
             };
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
             }
             bf16x8 Bf[2][8], Af[2][2][4];   // [parity of the half][row half h][hi i0 i1 | lo i0 i1]
             auto ldB = [&](int jj, bf16x8 (&Bv)[8]) {
-                const unsigned short *bt = ring + (jj & 3) * HS + boff;
+                const unsigned short *bt = ring + (jj % NS) * HS + boff;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     Bv[j] = *(const bf16x8 *)(bt + j * 16 * 32);
@@ -920,11 +922,23 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
             };
             auto ldA = [&](int jj, int h, bf16x8 (&A)[4]) {
                 const int to = tapl(jj), cc = 4 * (jj & 1) + g;
+                if constexpr (SHORT) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int o = win_off16(ar[2 * h + i] + to, cc);
-                    A[i] = *(const bf16x8 *)(win_h + o);
-                    A[2 + i] = *(const bf16x8 *)(win_l + o);
+                    for (int i = 0; i < 2; ++i) {
+                        const int o = win_off16(ar[2 * h + i] + to, cc);
+                        A[i] = *(const bf16x8 *)(win_h + o);
+                        A[2 + i] = *(const bf16x8 *)(win_l + o);
+                    }
+                } else {
+                    // rows r + 16 i: the rotation only sees (r & 6), so one address serves the four row blocks
+                    const int r = ar[0] + to;
+                    const int o = r * 64 + (((cc + (r & 6)) & 7) << 3);
+                    const unsigned short *ph = win_h + o, *pl = win_l + o;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        A[i] = *(const bf16x8 *)(ph + (2 * h + i) * 1024);
+                        A[2 + i] = *(const bf16x8 *)(pl + (2 * h + i) * 1024);
+                    }
                 }
             };
             auto mm = [&](int h, const bf16x8 (&A)[4], const bf16x8 (&Bv)[8]) {
@@ -942,10 +956,9 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
                     for (int j = 0; j < 4; ++j) acs[2 * h + i][j] = AC_MFMA16S(A[i], Bv[j], acs[2 * h + i][j]);
             };
             const int lasth = nhalf - 1;
-            issue_dma(0, 0);
-            issue_dma(1, 1);
-            issue_dma(2, 2 < lasth ? 2 : lasth);
-            __syncthreads();   // window visible, halves 0 .. 2 landed (a __syncthreads waits for the DMA queue as well)
+#pragma unroll
+            for (int q_ = 0; q_ < NS - 1; ++q_) issue_dma(q_, q_ < lasth ? q_ : lasth);
+            __syncthreads();   // window visible, halves 0 .. NS-2 landed (a __syncthreads waits for the DMA queue as well)
             ldB(0, Bf[0]);
             ldA(0, 0, Af[0][0]);
             ldA(0, 1, Af[0][1]);
@@ -956,18 +969,27 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
                             bf16x8 (&Anext)[2][4]) {
                 const int jn = j + 1 < lasth ? j + 1 : lasth;
                 const bool valid = GR == 1 || GR * (j >> 1) + grp < tc;
-                issue_dma(j + 3, j + 3 < lasth ? j + 3 : lasth);
+                issue_dma(j + NS - 1, j + NS - 1 < lasth ? j + NS - 1 : lasth);
                 __builtin_amdgcn_sched_barrier(0);
                 if (valid) mm(0, Acur[0], Bcur);
-                __builtin_amdgcn_sched_barrier(0);
                 ldB(jn, Bnext);
                 ldA(jn, 0, Anext[0]);
                 ldA(jn, 1, Anext[1]);
-                __builtin_amdgcn_sched_barrier(0);
                 if (valid) mm(1, Acur[1], Bcur);
+                // one fragment read per three MFMAs: issued back to back the 16 reads hold this wave's issue slot for
+                // ~100 cycles in which it feeds the matrix pipe nothing (and its SIMD partner is at the same point)
+                // (two MFMAs per read: the last read is issued 16 MFMAs before the half ends, so the wait in front of the
+                //  next half's first MFMA finds it landed)
+#pragma unroll
+                for (int q_ = 0; q_ < 16; ++q_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // all but this half's two DMA instructions are done: half j + 2 has landed in every wave's share
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                // all but the DMA instructions of the last NS - 3 halves are done: half j + 2 has landed in every
+                // wave's share of the ring
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 3)) : "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -1079,11 +1101,13 @@ int launch_x3(ConvWinParams &p, hipStream_t stream) {
     return AC_OK;
 }
 
-template <int WM, int WN, int GR>
+template <int WM, int WN, int GR, bool SHORT = false, int NS = 4>
 int launch_x3r(ConvWinParams &p, hipStream_t stream) {
     constexpr int BM = WM * 64, BN = WN * 64, NT = GR * WM * WN * 64;
     const ac_convwin_desc &d = p.d;
-    const size_t stages = (size_t)GR * 4 * 2 * BN * 32 * sizeof(short);   // ring of four half-stages per group
+    if (!SHORT && d.L < BM) return launch_x3r<WM, WN, GR, true, NS>(p, stream);
+    if (NS == 4 && d.variant == 6) return launch_x3r<WM, WN, GR, SHORT, 5>(p, stream);   // A/B: a fifth half-stage
+    const size_t stages = (size_t)GR * NS * 2 * BN * 32 * sizeof(short);   // ring of NS half-stages per group
     const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
     const int spt = d.L < BM ? BM / d.L : 1, Ls = d.L < BM ? d.L : BM;
     int TC = rows_budget / spt - Ls + 1;
@@ -1097,7 +1121,7 @@ int launch_x3r(ConvWinParams &p, hipStream_t stream) {
     p.vec_epi = 1;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3r_kernel<WM, WN, GR>,
+        hipError_t e = hipFuncSetAttribute((const void *)conv1d_window_x3r_kernel<WM, WN, GR, SHORT, NS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
@@ -1115,7 +1139,7 @@ int launch_x3r(ConvWinParams &p, hipStream_t stream) {
         hipError_t e = hipMemsetAsync(d.c, 0, (size_t)d.B * d.L * d.ldc * sizeof(float), stream);
         if (e != hipSuccess) return -(int)e - 2000;
     }
-    hipLaunchKernelGGL((conv1d_window_x3r_kernel<WM, WN, GR>), dim3(wgs, csplit), dim3(NT), lds, stream, p, TC);
+    hipLaunchKernelGGL((conv1d_window_x3r_kernel<WM, WN, GR, SHORT, NS>), dim3(wgs, csplit), dim3(NT), lds, stream, p, TC);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -1162,8 +1186,10 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
     const bool wide = d.N > 64;
     // N <= 64: one column of waves only -> a second wave group on the odd taps (needs a few taps to share)
     const bool two = !wide && d.k >= 4;
-    // variant 5: the ring kernel (weights by LDS-DMA into four half-stages, fragments prefetched across the barrier)
-    if (d.variant == 5 && (d.L % 256 == 0 || short_seq) && (wide || two))
+    // default (variant 0 / 5): the ring kernel (weights by LDS-DMA into four half-stages, fragments prefetched across
+    // the barrier); 6 = the same with a fifth half-stage; 4 = the round-2 kernel (two register-staged stages),
+    // 2 / 3 = its 32x32x16 / one-group forms (A/B measurements, tests)
+    if ((d.variant == 0 || d.variant == 5 || d.variant == 6) && (d.L % 256 == 0 || short_seq) && (wide || two))
         return wide ? launch_x3r<4, 2, 1>(p, stream) : launch_x3r<4, 1, 2>(p, stream);
     if (d.L % 256 == 0 || short_seq)
         return wide ? launch_x3<4, 2>(p, stream) : (two ? launch_x3<4, 1, true, 2>(p, stream) : launch_x3<4, 1>(p, stream));

@@ -31,6 +31,18 @@ __global__ void copy2d_kernel(const float *src, int64_t lds, float *dst, int64_t
         dst[r * ldd + c] = src[r * lds + c];
     }
 }
+// y[r, c] = pre[r, c] * colscale[c] + residual[r, c] (each factor optional), 4 columns per thread
+__global__ void scale_add_rows_kernel(const float *__restrict__ pre, const float *__restrict__ colscale,
+                                      const float *__restrict__ residual, float *__restrict__ y, int64_t n4,
+                                      int cols4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    GSTRIDE(i, n4) {
+        f32x4 v = ((const f32x4 *)pre)[i];
+        if (colscale) v *= ((const f32x4 *)colscale)[i % cols4];
+        if (residual) v += ((const f32x4 *)residual)[i];
+        ((f32x4 *)y)[i] = v;
+    }
+}
 __global__ void gather_cols_kernel(const float *src, int64_t lds, const int32_t *idx, float *dst,
                                    int64_t ldd, int64_t rows, int ncols) {
     const int64_t n = rows * ncols;
@@ -470,6 +482,14 @@ extern "C" int ac_copy2d(const float *src, int64_t lds, float *dst, int64_t ldd,
                          int32_t cols, ac_stream_t stream) {
     if (!src || !dst || rows < 0 || cols < 0) return AC_EINVAL;
     EW_LAUNCH(copy2d_kernel, rows * cols, src, lds, dst, ldd, rows, cols);
+}
+extern "C" int ac_scale_add_rows(const float *pre, const float *colscale, const float *residual, float *y,
+                                 int64_t rows, int32_t cols, ac_stream_t stream) {
+    if (!pre || !y || rows < 0 || cols <= 0) return AC_EINVAL;
+    if ((cols % 4) || !ac_aligned16(pre) || !ac_aligned16(y) || (colscale && !ac_aligned16(colscale)) ||
+        (residual && !ac_aligned16(residual)))
+        return AC_EALIGN;
+    EW_LAUNCH(scale_add_rows_kernel, rows * (cols / 4), pre, colscale, residual, y, rows * (cols / 4), cols / 4);
 }
 extern "C" int ac_gather_cols(const float *src, int64_t lds, const int32_t *idx, float *dst,
                               int64_t ldd, int64_t rows, int32_t ncols, ac_stream_t stream) {

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ dx,
     int64_t lddx, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ dxsum, int64_t rows, int act, unsigned short *__restrict__ dx16,
-    int64_t lddx16, int seg_len, int seg_pitch, int seg_off) {
+    int64_t lddx16, int seg_len, int seg_pitch, int seg_off, unsigned short *__restrict__ dxlo16) {
     constexpr int RPW = 64 / G, C = 4 * G * J;
     __shared__ __attribute__((aligned(16))) float sacc[3 * C];
     const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -422,6 +422,13 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
                 ushort4 h;
                 h.x = ln_bf16(o[0]); h.y = ln_bf16(o[1]); h.z = ln_bf16(o[2]); h.w = ln_bf16(o[3]);
                 *(ushort4 *)(dx16 + rr * lddx16 + 4 * (sub + G * j)) = h;
+                if (dxlo16) {
+                    // split-bf16 operand planes (math mode bf16x3): lo = bf16(dx - hi), same layout as hi
+                    ushort4 l;
+                    l.x = ln_bf16(o[0] - ac_h2f(h.x)); l.y = ln_bf16(o[1] - ac_h2f(h.y));
+                    l.z = ln_bf16(o[2] - ac_h2f(h.z)); l.w = ln_bf16(o[3] - ac_h2f(h.w));
+                    *(ushort4 *)(dxlo16 + rr * lddx16 + 4 * (sub + G * j)) = l;
+                }
             }
         }
     }
@@ -898,8 +905,20 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
                                 float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
                                 void *dx16, int64_t lddx16, int32_t seg_len, int32_t seg_pitch,
                                 int32_t seg_off, int32_t dy_bf16, int32_t x_bf16, ac_stream_t stream_) {
+    return ac_layernorm_bwd_split(dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx, dgamma, dbeta, dxsum, rows, C,
+                                  act, dx16, nullptr, lddx16, seg_len, seg_pitch, seg_off, dy_bf16, x_bf16, stream_);
+}
+
+extern "C" int ac_layernorm_bwd_split(const float *dy, int64_t lddy, const float *x, int64_t ldx,
+                                      const float *mean, const float *rstd, const float *gamma,
+                                      const float *beta, float *dx, int64_t lddx, float *dgamma,
+                                      float *dbeta, float *dxsum, int64_t rows, int32_t C, int32_t act,
+                                      void *dx16, void *dx16_lo, int64_t lddx16, int32_t seg_len,
+                                      int32_t seg_pitch, int32_t seg_off, int32_t dy_bf16, int32_t x_bf16,
+                                      ac_stream_t stream_) {
     if (!dy || !x || !mean || !rstd || !gamma || (!dx && !dx16) || rows < 0 || C <= 0)
         return AC_EINVAL;
+    if (dx16_lo && (!dx16 || ((uintptr_t)dx16_lo & 7u))) return AC_EINVAL;
     if (seg_len < 0 || (seg_len > 0 && (rows % seg_len || seg_pitch < seg_len + seg_off || seg_off < 0)))
         return AC_EINVAL;
     if (act == AC_ACT_GELU && !beta) return AC_EINVAL;
@@ -920,7 +939,8 @@ extern "C" int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, i
         const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 2048);
 #define LN_BWD_ARGS                                                                              \
     dim3(grid), dim3(ROWS_BLOCK), 0, stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx,    \
-        dgamma, dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len, seg_pitch, seg_off
+        dgamma, dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len, seg_pitch, seg_off,     \
+        (unsigned short *)dx16_lo
 #define LN_BWD_SUB(GG, JJ)                                                                       \
     if (G == GG && J == JJ) {                                                                    \
         if (x_bf16 && dy_bf16)                                                                   \

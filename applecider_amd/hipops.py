@@ -407,6 +407,17 @@ def _big(M, N, K) -> bool:
 
 
 _CONVWIN = True
+_LN_PLANES = True   # split-bf16: LayerNorm backward emits the (hi, lo) planes of d(conv outputs) (tests switch it)
+
+
+def _x3_bank_covered(B, L, Cin, Cout) -> bool:
+    """Every gradient product of a SpectraNet conv bank runs on the plane-fed kernels (ac_conv1d_window_x3 for the
+    input gradient, ac_conv1d_wgrad_bf16 for every k) — the shape rules of those entry points."""
+    short = L < 128 and L >= 8 and (L & (L - 1)) == 0 and (B * L) % 256 == 0
+    return (_CONVWIN and _CONVWIN_X3_FUSED and _WGRAD_WIN and Cout % 128 == 0 and Cin % 64 == 0 and L % 64 == 0
+            and (L % 128 == 0 or short))
+
+
 _CAT16 = True   # bf16 conv-bank output in front of the fused LayerNorm (bf16 math mode); tests switch it
 
 
@@ -599,6 +610,24 @@ def colsum(x2d_ptr, ld, rows, cols, device) -> torch.Tensor:
     return out
 
 
+_SMALL_GRID_SPLIT = True   # tests / A-B: False = one workgroup per output tile whatever the grid
+
+
+def _small_grid_split(M: int, N: int, K: int) -> int:
+    """Split-K factor of a product whose OUTPUT grid cannot fill the chip (fp32 data flow: f32 / bf16x3 modes).
+    A 128 x 128 tile per workgroup gives the ConvNeXt stage-2 / stage-3 products 108 / 24 workgroups on 256 CUs, one
+    wave per SIMD, and their 48 / 96 K tiles then run at the load -> split -> LDS -> barrier latency of a tile
+    (1.2 us) instead of its matrix-core time (0.35 us): 22-90 TFLOP/s.  Cut over K into >= 8-tile pieces until the
+    grid reaches ~2 workgroups per CU; the pieces meet in the output with fp32 atomics."""
+    if not _SMALL_GRID_SPLIT:
+        return 1
+    tiles = -(-M // 128) * -(-N // 128)
+    nkt = K // 32
+    if tiles > 128 or nkt < 16:
+        return 1
+    return max(1, min(512 // tiles, nkt // 8))
+
+
 # --------------------------------------------------------------------------- Linear
 class _Linear(Function):
     """y = [drop](act(x @ w.T + b) [* colscale]) [+ residual]   (nn.Linear + fused epilogue).
@@ -640,9 +669,27 @@ class _Linear(Function):
                  act=act, pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
                  math=_lib.MATH_BF16_IN)
         else:
-            gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
-                 pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
-                 drop_p=ctx.drop_p, drop_seed=ctx.drop_seed)
+            split = _small_grid_split(M, N, K) if (act == ACT_NONE and drop_p == 0.0 and N % 4 == 0) else 1
+            if split > 1:
+                # K pieces meet in `acc` (started at the bias) through atomics; layer scale / skip, which need the
+                # complete sum, follow as one elementwise pass
+                post = colscale is not None or residual is not None
+                acc = (pre if pre is not None else torch.empty_like(y)) if post else y
+                if b is not None:
+                    _lib.check(_lib_().ac_copy2d(_p(b), 0, _p(acc), N, M, N, _stream()), "ac_copy2d")
+                else:
+                    acc.zero_()
+                gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(acc), N), accumulate=2,
+                     split_k=split)
+                if post:
+                    _lib.check(_lib_().ac_scale_add_rows(_p(acc), _p(colscale), _p(residual), _p(y), M, N,
+                                                         _stream()), "ac_scale_add_rows")
+                elif pre is not None:
+                    pre.copy_(y)   # (not reached: save_pre implies colscale / GELU / ReLU + residual)
+            else:
+                gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
+                     pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
+                     drop_p=ctx.drop_p, drop_seed=ctx.drop_seed)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.shape_x = x.shape
         ctx.has_b = b is not None
@@ -719,7 +766,13 @@ class _Linear(Function):
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
                      math=_lib.MATH_BF16_IN)
             else:
-                gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
+                split = _small_grid_split(M, K, N)
+                if split > 1:
+                    dx.zero_()
+                    gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), accumulate=2,
+                         split_k=split)
+                else:
+                    gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
             if not _is16only(dx):
                 dx = dx.reshape(ctx.shape_x)
             elif dx.shape != ctx.shape_x:
@@ -1721,6 +1774,7 @@ class _ConvGroup1d(Function):
         need_dx = Cin != 1 and ctx.needs_input_grad[0]
         Lpd = L + 2 * Pmax
         dypad = dyop = None
+        planes_direct, ctx_dyplanes = False, None
         if ctx.fused_ln:
             saved = ctx.saved_tensors
             xpad, ws = saved[0], list(saved[1:1 + nconv])
@@ -1736,7 +1790,21 @@ class _ConvGroup1d(Function):
             # gradient of the conv outputs is never materialised
             direct16 = b16 and fuse_bias and _ln_sub_shape(Ncat)
             dpre, seg = None, (0, 0, 0)
-            if direct16 and need_dx:
+            # split-bf16 mode: LayerNorm's backward writes the (hi, lo) operand planes of the gradient products
+            # itself, zero-padded — no fp32 d(ycat) and no ac_pad_rows_split pass (0.65 ms per step at B = 512) —
+            # when every product of the bank runs on the plane-fed kernels (nothing then reads the fp32 form)
+            planes_direct = (_LN_PLANES and not b16 and x3_mode() and need_dx and fuse_bias and _ln_sub_shape(Ncat)
+                             and getattr(ctx, "xplanes", None) is not None and dy16in is None and not ctx.cat16
+                             and _x3_bank_covered(B, L, Cin, Cout))
+            lo16 = None
+            if planes_direct:
+                both = torch.empty(2, B, Lpd, Ncat, device=dev, dtype=_H16)
+                if Pmax > 0:
+                    both[:, :, :Pmax].zero_()
+                    both[:, :, Pmax + L:].zero_()
+                out16, lo16, seg = both[0], both[1], (L, Lpd, Pmax)
+                ctx_dyplanes = (both[0], both[1])
+            elif direct16 and need_dx:
                 dypad = torch.empty(B, Lpd, Ncat, device=dev, dtype=_H16)
                 if Pmax > 0:
                     dypad[:, :Pmax].zero_()
@@ -1747,14 +1815,14 @@ class _ConvGroup1d(Function):
                 out16 = dyop
             else:
                 dpre, out16 = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32), None
-            _lib.check(_lib_().ac_layernorm_bwd(_p(dy16in if dy16in is not None else dycat), Ncat,
-                                                _p(ycat), Ncat, _p(mean), _p(rstd),
-                                                _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
-                                                _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
-                                                _p(out16), Ncat, seg[0], seg[1], seg[2],
-                                                1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
-                                                _stream()),
-                       "ac_layernorm_bwd")
+            _lib.check(_lib_().ac_layernorm_bwd_split(_p(dy16in if dy16in is not None else dycat), Ncat,
+                                                      _p(ycat), Ncat, _p(mean), _p(rstd),
+                                                      _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
+                                                      _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
+                                                      _p(out16), _p(lo16), Ncat, seg[0], seg[1], seg[2],
+                                                      1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
+                                                      _stream()),
+                       "ac_layernorm_bwd_split")
             dycat = dpre
             if ln_direct:
                 dgam = dbet = None
@@ -1801,7 +1869,7 @@ class _ConvGroup1d(Function):
         else:
             if need_dx:
                 dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
-            dyplanes = _pad_rows_split(dycat, B, L, Ncat, Pmax, Lpd) if x3win else None
+            dyplanes = ctx_dyplanes if planes_direct else (_pad_rows_split(dycat, B, L, Ncat, Pmax, Lpd) if x3win else None)
             for j, k in enumerate(ksizes):
                 p = k // 2
                 off = Pmax - p
@@ -1809,6 +1877,9 @@ class _ConvGroup1d(Function):
                         dyplanes, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, split16_wT(ctx.params[0][j]),
                         Cout, Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):
                     pass
+                elif ctx.needs_input_grad[0] and planes_direct:
+                    raise RuntimeError("split-bf16 conv bank: the plane-fed window kernel refused a shape that "
+                                       "_x3_bank_covered() admits")
                 elif ctx.needs_input_grad[0]:
                     goff = _table(("cg_dx", Ncat, Cout, j, k, Pmax),
                                   lambda j=j, k=k, p=p: [(Pmax + p - t) * Ncat + j * Cout + cb * 32
@@ -1854,7 +1925,7 @@ class _ConvGroup1d(Function):
                     done = conv_wgrad(dyplanes[0], dyplanes[1], Lpd * Ncat, Ncat, Pmax, j * Cout,
                                       ctx.xplanes[0], ctx.xplanes[1], Lp * Cin, Cin, off, Lp, B, L, Cout, Cin, k, dw)
                 if not done:
-                    if xpad is None:
+                    if xpad is None or planes_direct:
                         raise RuntimeError("split-bf16 conv bank: the weight-gradient kernel refused a covered shape")
                     tile_, split_ = _tn_plan(Cout, k * Cin, B * L) if b16 else (0, _split_for(Cout, k * Cin, B * L))
                     gemm(AC_GEMM_TN, Cout, k * Cin, B * L, dy_mat(j),

@@ -176,7 +176,10 @@ typedef struct ac_convwin_desc {
     int64_t ldc;
     const float *bias;
     int32_t accumulate; /* 0 store, 1 out += */
-    int32_t variant;    /* 0 auto; 1: never use the 8-wave two-group kernel for N <= 64 (A/B tests) */
+    int32_t variant;    /* 0 auto.  ac_conv1d_window_bf16: 1 = never use the 8-wave two-group kernel for N <= 64.
+                           ac_conv1d_window_x3: 4 = the round-2 kernel (register-staged weight stages) instead of
+                           the LDS-DMA ring kernel, 2 / 3 = its 32x32x16 / one-group forms, 6 = ring of five
+                           (A/B measurements, tests) */
     void *c16;          /* nullable: bf16 output (element (b, l, n) at c16 + (b*L + l)*ldc16 + n);
                            c may then be NULL (bf16-only output, accumulate must be 0) */
     int64_t ldc16;
@@ -212,6 +215,15 @@ int ac_layernorm_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx,
                      int64_t rows, int32_t C, int32_t act, void *dx16, int64_t lddx16,
                      int32_t seg_len, int32_t seg_pitch, int32_t seg_off, int32_t dy_bf16,
                      int32_t x_bf16, ac_stream_t stream);
+/* The same with a second 16-bit output: dx16_lo (nullable) receives bf16(dx - dx16), the lo plane of the split-bf16
+ * operand pair (math mode bf16x3) in the layout of dx16 — LayerNorm's backward then writes the (hi, lo) planes
+ * of the Conv1d gradient products itself and no fp32 dx (dx = NULL) nor a separate split pass is needed. */
+int ac_layernorm_bwd_split(const float *dy, int64_t lddy, const float *x, int64_t ldx,
+                           const float *mean, const float *rstd, const float *gamma, const float *beta,
+                           float *dx, int64_t lddx, float *dgamma, float *dbeta, float *dxsum,
+                           int64_t rows, int32_t C, int32_t act, void *dx16, void *dx16_lo, int64_t lddx16,
+                           int32_t seg_len, int32_t seg_pitch, int32_t seg_off, int32_t dy_bf16,
+                           int32_t x_bf16, ac_stream_t stream);
 /* dx16 (nullable, same C restriction as y16; dx may then be NULL): bf16 copy of dx.  With
  * seg_len > 0 row r = (b, l), l < seg_len, is written to row b*seg_pitch + seg_off + l of dx16 —
  * the zero-padded [B, Lp, C] operand of the Conv1d gradient products (pads are the caller's).
@@ -247,6 +259,11 @@ int ac_act_fwd(const float *x, float *y, int64_t n, int32_t kind, ac_stream_t st
 /* 2-D strided copy: dst[r, c] = src[r, c]. */
 int ac_copy2d(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows,
               int32_t cols, ac_stream_t stream);
+/* y[r, c] = pre[r, c] * colscale[c] + residual[r, c] on contiguous [rows, cols] matrices (colscale / residual
+ * nullable; cols % 4 == 0): the layer-scale + skip epilogue of a ConvNeXt block's fc2 (timm convnext_tiny,
+ * astrominn.py:12-17) when that product ran split over K with atomics and could not carry it itself. */
+int ac_scale_add_rows(const float *pre, const float *colscale, const float *residual, float *y, int64_t rows,
+                      int32_t cols, ac_stream_t stream);
 /* dst[r, j] = src[r, idx[j]]  — metadata column gathers, astrominn.py:249-261. */
 int ac_gather_cols(const float *src, int64_t lds, const int32_t *idx, float *dst, int64_t ldd,
                    int64_t rows, int32_t ncols, ac_stream_t stream);

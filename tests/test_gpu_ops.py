@@ -948,3 +948,50 @@ def test_batchnorm_large_mean_many_rows_vs_torch(dev):
     assert rel(x.grad, x64.grad) <= 2e-3
     assert rel(gamma.grad, g64.grad) <= 1e-3
     assert rel(beta.grad, b64.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("M,K,N,scale_res", [(512, 3072, 768, True), (4608, 1536, 384, True), (512, 3072, 384, False),
+                                             (300, 1024, 100, False)])
+def test_linear_small_grid_split_k(dev, mode, M, K, N, scale_res):
+    """Long-reduction products whose output grid leaves most CUs idle (ConvNeXt stage 2 / 3 fc2 and the input
+    gradient of fc1, SpectraNet's 3072 -> 384 head; timm block astrominn.py:12-17, spectranet.py:138-155) are cut
+    over K and meet in the output with atomics; bias starts the sum, layer scale and skip follow in one pass.
+    Same results as the one-workgroup-per-tile form and as torch in fp64, forward and all gradients."""
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    try:
+        gen = torch.Generator().manual_seed(M + N)
+        x0 = torch.randn(M, K, generator=gen)
+        w0 = torch.randn(N, K, generator=gen) / math.sqrt(K)
+        b0 = torch.randn(N, generator=gen)
+        cs0 = torch.randn(N, generator=gen) if scale_res else None
+        r0 = torch.randn(M, N, generator=gen) if scale_res else None
+        go = torch.randn(M, N, generator=gen)
+        assert H._small_grid_split(M, N, K) > 1 and H._small_grid_split(M, K, N) > 1
+        x64, w64, b64 = (t.double().requires_grad_() for t in (x0, w0, b0))
+        y64 = x64 @ w64.t() + b64
+        if scale_res:
+            cs64, r64 = cs0.double().requires_grad_(), r0.double().requires_grad_()
+            y64 = y64 * cs64 + r64
+        y64.backward(go.double())
+        res = {}
+        for split in (True, False):
+            H._SMALL_GRID_SPLIT = split
+            try:
+                x, w, b = (t.clone().to(dev).requires_grad_() for t in (x0, w0, b0))
+                cs = cs0.clone().to(dev).requires_grad_() if scale_res else None
+                r = r0.clone().to(dev).requires_grad_() if scale_res else None
+                y = H.linear(x, w, b, residual=r, colscale=cs)
+                y.backward(go.to(dev))
+                torch.cuda.synchronize()
+            finally:
+                H._SMALL_GRID_SPLIT = True
+            res[split] = [y.detach(), x.grad, w.grad, b.grad] + ([cs.grad, r.grad] if scale_res else [])
+        want = [y64.detach(), x64.grad, w64.grad, b64.grad] + ([cs64.grad, r64.grad] if scale_res else [])
+        tol = 2e-5 if mode == "bf16x3" else 5e-6
+        for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
+            close(a, b_, tol=tol, name=f"split vs plain [{i}]")
+            close(a, w_, tol=5e-5, name=f"split vs fp64 [{i}]")
+    finally:
+        H.set_math("f32")

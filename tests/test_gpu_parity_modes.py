@@ -257,7 +257,7 @@ def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
 
 
 @pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
-@pytest.mark.parametrize("fused", [True, False, "ring"])
+@pytest.mark.parametrize("fused", [True, False, "round2"])
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (2, 128, 128, 64, (3, 15, 61)),
                                              (1, 256, 256, 128, (7, 13, 31)), (2, 64, 128, 256, (3, 15, 61)),
                                              (8, 64, 128, 256, (3, 11, 31)), (32, 16, 512, 128, (3, 7, 13)),
@@ -281,10 +281,10 @@ def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
     xd = x.detach().float().permute(0, 2, 1).contiguous().to(dev).requires_grad_()
     wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
     bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
-    # "ring": the round-3 kernel (weights by LDS-DMA into a ring of half-stages, fragments prefetched across the
-    # barrier); shapes it does not cover fall through to the round-2 kernel inside the library
+    # True: the default = the round-3 ring kernel (weights by LDS-DMA into a ring of half-stages, fragments prefetched
+    # across the barrier) where it applies; "round2": the round-2 kernel everywhere; False: three bf16 passes
     H._CONVWIN_X3_FUSED = bool(fused)
-    H._X3_VARIANT = 5 if fused == "ring" else 0
+    H._X3_VARIANT = 4 if fused == "round2" else 0
     try:
         yd = H.conv_group1d(xd, ks, wd, bd)
         yd.backward(go.float().permute(0, 2, 1).contiguous().to(dev))
@@ -298,3 +298,44 @@ def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
     for i, k in enumerate(ks):
         assert rel(wd[i].grad.reshape(Cout, k, Cin).permute(0, 2, 1), ws[i].grad) <= tol, f"dw{i}"
         assert rel(bd[i].grad, bs[i].grad) <= tol
+
+
+@pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
+@pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (4, 64, 128, 256, (3, 11, 31))])
+def test_conv_bank_layernorm_backward_writes_the_operand_planes(dev, math_mode, B, L, Cin, Cout, ks):
+    """SpectraNetBlock = conv bank -> LayerNorm -> GELU (spectranet.py:18-35).  In split-bf16 mode LayerNorm's
+    backward emits the zero-padded (hi, lo) planes of d(conv outputs) itself (ac_layernorm_bwd_split) instead of
+    an fp32 tensor that ac_pad_rows_split then re-reads: every gradient must equal the two-pass form (same plane
+    values; the weight-gradient atomics reorder sums) and torch's fp64 backward."""
+    import math
+    import torch.nn.functional as F
+    from applecider_amd import hipops as H
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, L, generator=gen, dtype=torch.float64).requires_grad_()
+    ws = [(torch.randn(Cout, Cin, k, generator=gen, dtype=torch.float64) / math.sqrt(Cin * k)).requires_grad_() for k in ks]
+    bs = [torch.randn(Cout, generator=gen, dtype=torch.float64).requires_grad_() for _ in ks]
+    gam = (1 + 0.1 * torch.randn(3 * Cout, generator=gen, dtype=torch.float64)).requires_grad_()
+    bet = (0.1 * torch.randn(3 * Cout, generator=gen, dtype=torch.float64)).requires_grad_()
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    z = F.gelu(F.layer_norm(y.permute(0, 2, 1), (3 * Cout,), gam, bet, 1e-5))
+    go = torch.randn(*z.shape, generator=gen, dtype=torch.float64)
+    z.backward(go)
+    res = {}
+    for planes in (True, False):
+        H._LN_PLANES = planes
+        try:
+            xd = x.detach().float().permute(0, 2, 1).contiguous().to(dev).requires_grad_()
+            wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+            bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
+            gd, btd = gam.detach().float().to(dev).requires_grad_(), bet.detach().float().to(dev).requires_grad_()
+            zd = H.conv_group1d(xd, ks, wd, bd, ln=(gd, btd, 1e-5))
+            zd.backward(go.float().to(dev))
+            torch.cuda.synchronize()
+        finally:
+            H._LN_PLANES = True
+        res[planes] = [xd.grad] + [w.grad for w in wd] + [b.grad for b in bd] + [gd.grad, btd.grad]
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+    want = [x.grad.permute(0, 2, 1)] + [w.grad.permute(0, 2, 1).reshape(Cout, -1) for w in ws] + [b.grad for b in bs] + [gam.grad, bet.grad]
+    for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
+        assert rel(a, b_) <= 2e-6, (i, rel(a, b_))
+        assert rel(a, w_) <= 1e-4, (i, rel(a, w_))

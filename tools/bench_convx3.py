@@ -14,7 +14,7 @@ from applecider_amd import hipops as H
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-variants = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0,5").split(",")]
+variants = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "4,0").split(",")]
 dev = torch.device("cuda:0")
 H.set_math("bf16x3")
 torch.manual_seed(0)
