@@ -111,6 +111,7 @@ SIGNATURES = {
     "ac_act_fwd": [_P, _P, _I64, _I32, _P],
     "ac_copy2d": [_P, _I64, _P, _I64, _I64, _I32, _P],
     "ac_scale_add_rows": [_P, _P, _P, _P, _I64, _I32, _P],
+    "ac_splitk_reduce": [_P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "ac_gather_cols": [_P, _I64, _P, _P, _I64, _I64, _I32, _P],
     "ac_gate_fwd": [_P, _P, _P, _P, _I64, _P],
     "ac_gate_bwd": [_P, _P, _P, _P, _P, _I64, _P],

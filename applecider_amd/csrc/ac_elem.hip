@@ -43,6 +43,23 @@ __global__ void scale_add_rows_kernel(const float *__restrict__ pre, const float
         ((f32x4 *)y)[i] = v;
     }
 }
+// y = ((sum_s part[s]) + bias -> pre_out) * colscale + residual, slabs summed in index order (deterministic)
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, int split, const float *__restrict__ bias,
+                                     float *__restrict__ pre_out, const float *__restrict__ colscale,
+                                     const float *__restrict__ residual, float *__restrict__ y, int64_t n4,
+                                     int cols4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    GSTRIDE(i, n4) {
+        f32x4 v = ((const f32x4 *)part)[i];
+        for (int s = 1; s < split; ++s) v += ((const f32x4 *)part)[(int64_t)s * n4 + i];
+        const int c = (int)(i % cols4);
+        if (bias) v += ((const f32x4 *)bias)[c];
+        if (pre_out) ((f32x4 *)pre_out)[i] = v;
+        if (colscale) v *= ((const f32x4 *)colscale)[c];
+        if (residual) v += ((const f32x4 *)residual)[i];
+        ((f32x4 *)y)[i] = v;
+    }
+}
 __global__ void gather_cols_kernel(const float *src, int64_t lds, const int32_t *idx, float *dst,
                                    int64_t ldd, int64_t rows, int ncols) {
     const int64_t n = rows * ncols;
@@ -490,6 +507,17 @@ extern "C" int ac_scale_add_rows(const float *pre, const float *colscale, const 
         (residual && !ac_aligned16(residual)))
         return AC_EALIGN;
     EW_LAUNCH(scale_add_rows_kernel, rows * (cols / 4), pre, colscale, residual, y, rows * (cols / 4), cols / 4);
+}
+extern "C" int ac_splitk_reduce(const float *part, int32_t split, const float *bias, float *pre_out,
+                                const float *colscale, const float *residual, float *y, int64_t rows, int32_t cols,
+                                ac_stream_t stream) {
+    if (!part || !y || split < 1 || rows < 0 || cols <= 0) return AC_EINVAL;
+    if ((cols % 4) || !ac_aligned16(part) || !ac_aligned16(y) || (bias && !ac_aligned16(bias)) ||
+        (pre_out && !ac_aligned16(pre_out)) || (colscale && !ac_aligned16(colscale)) ||
+        (residual && !ac_aligned16(residual)) || ((rows * cols) % 4))
+        return AC_EALIGN;
+    EW_LAUNCH(splitk_reduce_kernel, rows * (cols / 4), part, split, bias, pre_out, colscale, residual, y,
+              rows * (cols / 4), cols / 4);
 }
 extern "C" int ac_gather_cols(const float *src, int64_t lds, const int32_t *idx, float *dst,
                               int64_t ldd, int64_t rows, int32_t ncols, ac_stream_t stream) {

@@ -120,6 +120,26 @@ __device__ __forceinline__ void store_tile_atomic(const ac_gemm_desc &d, const f
     });
 }
 
+// Deterministic split-K (accumulate = 3): K piece s stores its partial tile plainly into slab s of a [split_k, M, N]
+// buffer; a reduce pass (ac_splitk_reduce) sums the slabs in a fixed order and applies the epilogue.  Forward
+// products use this instead of atomics: two runs of the same forward stay bit-identical.
+__device__ __forceinline__ void store_tile_slab(const ac_gemm_desc &d, const f32x16 (&acc)[2][2], int split,
+                                                int row_base, int col_base, int li, int lh) {
+    const int n0 = col_base + li, n1 = n0 + 32;
+    const bool v0 = n0 < d.N, v1 = n1 < d.N;
+    float *c = (float *)d.c.ptr + (int64_t)split * d.M * d.N + n0;
+    const float alpha = d.alpha;
+    static_for<0, 32>([&](auto idx) {
+        constexpr int sa = decltype(idx)::value / 16, e = decltype(idx)::value % 16;
+        const int m = row_base + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < d.M) {
+            float *cr = c + (int64_t)m * d.N;
+            if (v0) cr[0] = acc[sa][0][e] * alpha;
+            if (v1) cr[32] = acc[sa][1][e] * alpha;
+        }
+    });
+}
+
 // 16-byte epilogue: the wave parks each 32x64 half of its accumulator tile in 8 KB of (now idle)
 // LDS and re-reads it row-major, so every lane handles 4 consecutive columns of one row: bias /
 // aux / residual come in as float4 and C goes out as float4 — 4x fewer memory instructions than the
@@ -495,7 +515,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    if (p.vec_epi == 2)
+    if (p.vec_epi == 3)
+        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
         store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
@@ -631,7 +653,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    if (p.vec_epi == 2)
+    if (p.vec_epi == 3)
+        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
         store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
@@ -971,7 +995,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    if (p.vec_epi == 2)
+    if (p.vec_epi == 3)
+        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+    else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
         store_tile_vec(d, dseed, p.epi_var, acc, smem + wave * 2048, tm * BM + wm * 64, tn * BN + wn * 64, lane);
@@ -1394,6 +1420,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     GemmParams p;
     p.d = d;
     if (!use_mfma) {
+        if (d.accumulate == 3) return AC_EINVAL;   // split-K slabs exist on the matrix-core kernels only
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.
         p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = p.vec_epi = 0;
@@ -1410,11 +1437,15 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
-    if (d.split_k > 1) p.d.accumulate = 2;
+    const bool slabs = d.accumulate == 3;   // deterministic split-K: c is [split_k, M, N], reduced by ac_splitk_reduce
+    if (slabs && (d.math == AC_MATH_BF16 || d.bias || d.pre_out || d.act || d.dact || d.residual || d.colscale ||
+                  d.mask16 || d.c16 || d.drop_p > 0.f || d.c.rows.r1 != 0 || d.c.goff || d.c.rows.s3 != d.N))
+        return AC_EINVAL;
+    if (d.split_k > 1 && !slabs) p.d.accumulate = 2;
     if (d.split_k == 1 && d.accumulate == 2) p.d.accumulate = 1;  // one workgroup per tile: plain +=
     if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
-    p.vec_epi = vec_epilogue_ok(p.d, p.d.accumulate);
-    p.epi_var = epilogue_variant(p.d, p.d.accumulate);
+    p.vec_epi = slabs ? 3 : vec_epilogue_ok(p.d, p.d.accumulate);
+    p.epi_var = slabs ? EPI_GENERIC : epilogue_variant(p.d, p.d.accumulate);
     p.tiles_m = (d.M + BM - 1) / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.nkt = (d.K + BK - 1) / BK;

@@ -619,7 +619,7 @@ def _small_grid_split(M: int, N: int, K: int) -> int:
     wave per SIMD, and their 48 / 96 K tiles then run at the load -> split -> LDS -> barrier latency of a tile
     (1.2 us) instead of its matrix-core time (0.35 us): 22-90 TFLOP/s.  Cut over K into >= 8-tile pieces until the
     grid reaches ~2 workgroups per CU; the pieces meet in the output with fp32 atomics."""
-    if not _SMALL_GRID_SPLIT:
+    if not _SMALL_GRID_SPLIT or (M % 4) or (N % 4) or (K % 4):
         return 1
     tiles = -(-M // 128) * -(-N // 128)
     nkt = K // 32
@@ -671,21 +671,13 @@ class _Linear(Function):
         else:
             split = _small_grid_split(M, N, K) if (act == ACT_NONE and drop_p == 0.0 and N % 4 == 0) else 1
             if split > 1:
-                # K pieces meet in `acc` (started at the bias) through atomics; layer scale / skip, which need the
-                # complete sum, follow as one elementwise pass
-                post = colscale is not None or residual is not None
-                acc = (pre if pre is not None else torch.empty_like(y)) if post else y
-                if b is not None:
-                    _lib.check(_lib_().ac_copy2d(_p(b), 0, _p(acc), N, M, N, _stream()), "ac_copy2d")
-                else:
-                    acc.zero_()
-                gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(acc), N), accumulate=2,
+                # forward stays bit-reproducible: every K piece stores its partial tile into its own slab, one pass
+                # sums the slabs in order and applies bias / layer scale / skip (which need the complete sum)
+                part = torch.empty(split, M, N, device=x.device, dtype=torch.float32)
+                gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(part), N), accumulate=3,
                      split_k=split)
-                if post:
-                    _lib.check(_lib_().ac_scale_add_rows(_p(acc), _p(colscale), _p(residual), _p(y), M, N,
-                                                         _stream()), "ac_scale_add_rows")
-                elif pre is not None:
-                    pre.copy_(y)   # (not reached: save_pre implies colscale / GELU / ReLU + residual)
+                _lib.check(_lib_().ac_splitk_reduce(_p(part), split, _p(b), _p(pre), _p(colscale), _p(residual),
+                                                    _p(y), M, N, _stream()), "ac_splitk_reduce")
             else:
                 gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
                      pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,

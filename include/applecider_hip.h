@@ -74,7 +74,8 @@ const char *ac_strerror(int code);
  *   if residual: v += residual[m,n];
  *   if c16: c16[m,n] = bf16(v)  (row stride ld_c16, columns through c.goff when that is set;
  *           c.ptr may then be NULL: bf16-only output);
- *   accumulate: 0 store, 1 C += v, 2 atomicAdd(C, v)  (2 is forced by split_k > 1).
+ *   accumulate: 0 store, 1 C += v, 2 atomicAdd(C, v)  (2 is forced by split_k > 1), 3 = split-K slabs: C is
+ *   [split_k, M, N] and K piece s stores alpha*acc into slab s (no epilogue; see ac_splitk_reduce).
  * mask16 is a bf16 matrix: with act = RELU (and dropout) in the forward product, the forward's bf16
  * output is its own backward mask — alpha = 1/(1-p) then rebuilds dropout's scale
  * (Time2Vec.py:96-101 feed-forward: linear2(dropout(relu(linear1(x))))).
@@ -264,6 +265,13 @@ int ac_copy2d(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t ro
  * astrominn.py:12-17) when that product ran split over K with atomics and could not carry it itself. */
 int ac_scale_add_rows(const float *pre, const float *colscale, const float *residual, float *y, int64_t rows,
                       int32_t cols, ac_stream_t stream);
+/* Deterministic split-K: ac_gemm with accumulate = 3 and split_k = S (fp32 / split-bf16 math, plain [M, N] output,
+ * no epilogue) stores the partial product of K piece s into slab s of c = [S, M, N]; this pass sums the slabs in
+ * index order and applies the epilogue the product could not:
+ *     v = sum_s part[s] (+ bias[c]);  pre_out = v (nullable);  y = v (* colscale[c]) (+ residual).
+ * Used for forward products whose output grid leaves the chip idle (cols % 4 == 0). */
+int ac_splitk_reduce(const float *part, int32_t split, const float *bias, float *pre_out, const float *colscale,
+                     const float *residual, float *y, int64_t rows, int32_t cols, ac_stream_t stream);
 /* dst[r, j] = src[r, idx[j]]  — metadata column gathers, astrominn.py:249-261. */
 int ac_gather_cols(const float *src, int64_t lds, const int32_t *idx, float *dst, int64_t ldd,
                    int64_t rows, int32_t ncols, ac_stream_t stream);
