@@ -619,8 +619,8 @@ def _small_grid_split(M: int, N: int, K: int) -> int:
     wave per SIMD, and their 48 / 96 K tiles then run at the load -> split -> LDS -> barrier latency of a tile
     (1.2 us) instead of its matrix-core time (0.35 us): 22-90 TFLOP/s.  Cut over K into >= 8-tile pieces until the
     grid reaches ~2 workgroups per CU; the pieces meet in the output with fp32 atomics."""
-    if not _SMALL_GRID_SPLIT or (M % 4) or (N % 4) or (K % 4):
-        return 1
+    if not _SMALL_GRID_SPLIT or (M % 4) or (N % 4) or (K % 4) or not _big(M, N, K):
+        return 1   # (below _big the library runs its scalar kernel, which has no split form)
     tiles = -(-M // 128) * -(-N // 128)
     nkt = K // 32
     if tiles > 128 or nkt < 16:

@@ -968,7 +968,7 @@ def test_linear_small_grid_split_k(dev, mode, M, K, N, scale_res):
         cs0 = torch.randn(N, generator=gen) if scale_res else None
         r0 = torch.randn(M, N, generator=gen) if scale_res else None
         go = torch.randn(M, N, generator=gen)
-        assert H._small_grid_split(M, N, K) > 1 and H._small_grid_split(M, K, N) > 1
+        assert H._small_grid_split(M, N, K) > 1     # (the input gradient splits too when ITS grid is small)
         x64, w64, b64 = (t.double().requires_grad_() for t in (x0, w0, b0))
         y64 = x64 @ w64.t() + b64
         if scale_res:
