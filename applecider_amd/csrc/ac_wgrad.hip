@@ -317,6 +317,12 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     }
 }
 
+// Round 3, measured and NOT kept: the same product on a ring of four LDS-DMA half-steps with the fragments of the
+// next half read under the MFMAs of this one (the recipe that gave conv1d_window_x3r_kernel +7 %): 8.18 ms against
+// 7.54 ms for this kernel over the nine stage-2..4 products (profiles/r03_wgrad_ring_ab.txt).  Both operands are
+// re-streamed every step here (26 DMA instructions per half against 16 in the window kernel, each ~60-100 issue
+// cycles of a wave that then feeds the matrix pipe nothing), the barrier interval halves, and the input rows' halo
+// is fetched twice; this kernel's 192 MFMAs per wave and barrier already hide most of what the ring removes.
 template <bool SPLIT, bool S16, bool SHORT = false>
 int launch_wgrad(WgradParams &p, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
