@@ -479,8 +479,11 @@ __device__ __forceinline__ void dma_plane(float *buf, const float *src, int C, i
 }
 
 // SLOTS row slots per workgroup (threads = 32 channels x SLOTS), ROUNDS = rows per slot
-template <int W, int SLOTS>
-__global__ __launch_bounds__(32 * SLOTS, 2) void dwconv_pipe_fwd_kernel(const float *__restrict__ x,
+// PROBE (diagnostic builds of the same kernel, variant 8 / 9 of ac_dwconv7x7_fwd_v; results are NOT a convolution):
+// 1 = the memory side alone (each output row = the centre input row: DMA, LDS reads of one row, stores), 2 = no
+// stores (taps only) — where the 27 us of the real kernel go (profiles/r03_dwconv_probe.txt).
+template <int W, int SLOTS, int PROBE = 0>
+__global__ __launch_bounds__(32 * SLOTS, (SLOTS * 64) / 256) void dwconv_pipe_fwd_kernel(const float *__restrict__ x,
                                                                       const float *__restrict__ w,
                                                                       const float *__restrict__ bias,
                                                                       float *__restrict__ y, int B, int C, int ncg) {
@@ -523,13 +526,26 @@ __global__ __launch_bounds__(32 * SLOTS, 2) void dwconv_pipe_fwd_kernel(const fl
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) {
                 const int yy = py + ky - 3;
+                if (PROBE == 1 && ky != 3) continue;
                 if (yy >= 0 && yy < W) {
                     float in[W];
 #pragma unroll
                     for (int j = 0; j < W; ++j) in[j] = pb[(yy * W + j) * CG];
-                    row_taps<W, false>(in, wt, ky, out);
+                    if (PROBE == 1) {
+#pragma unroll
+                        for (int j = 0; j < W; ++j) out[j] += in[j] * wt[24];
+                    } else {
+                        row_taps<W, false>(in, wt, ky, out);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (PROBE == 2) {   // keep the sums alive, store one value per row
+                float acc_ = 0.f;
+#pragma unroll
+                for (int o = 0; o < W; ++o) acc_ += out[o];
+                if (acc_ == 123.456f) yb[(int64_t)py * W * C] = acc_;
+                continue;
             }
             float *yp = yb + (int64_t)py * W * C;
             // W store instructions per round in EVERY wave — the count the vmcnt below relies on.  A slot without a
@@ -546,29 +562,32 @@ __global__ __launch_bounds__(32 * SLOTS, 2) void dwconv_pipe_fwd_kernel(const fl
             // all but the youngest ROUNDS * W vector-memory operations (this item's stores) are done: the DMA of
             // the next plane, issued before them, has landed
             static_assert(ROUNDS * W <= 63, "vmcnt field");
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS * W) : "memory");
+            if (PROBE == 2)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS * W) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         cur ^= 1;
     }
 }
 
-template <int W, int SLOTS>
+template <int W, int SLOTS, int PROBE = 0>
 int launch_pipe_fwd(const float *x, const float *w, const float *bias, float *y, int B, int C, hipStream_t stream) {
     const int ncg = C / CG;
     const size_t lds = (size_t)2 * PipeGeo<W>::PLANE * sizeof(float);
-    const int per_cu = (int)((160 * 1024) / lds) < (2048 / (32 * SLOTS)) ? (int)((160 * 1024) / lds) : (2048 / (32 * SLOTS));
+    const int per_cu = (int)((160 * 1024) / lds) < (2048 / (32 * SLOTS)) ? (int)((160 * 1024) / lds) : (2048 / (32 * SLOTS));   // LDS- or thread-limited
     int wgs = 256 * (per_cu < 1 ? 1 : per_cu);
     wgs -= wgs % ncg;
     if (wgs > B * ncg) wgs = B * ncg;
     static bool configured = false;
     if (!configured && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_fwd_kernel<W, SLOTS>,
+        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_fwd_kernel<W, SLOTS, PROBE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
-    hipLaunchKernelGGL((dwconv_pipe_fwd_kernel<W, SLOTS>), dim3(wgs), dim3(32 * SLOTS), lds, stream, x, w, bias, y, B, C, ncg);
+    hipLaunchKernelGGL((dwconv_pipe_fwd_kernel<W, SLOTS, PROBE>), dim3(wgs), dim3(32 * SLOTS), lds, stream, x, w, bias, y, B, C, ncg);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -898,8 +917,13 @@ extern "C" int ac_dwconv7x7_fwd_v(const float *x, const float *w, const float *b
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     // pipelined persistent kernels (variant 0 = automatic, 1 = the one-item-per-workgroup kernels below)
+    if ((variant == 8 || variant == 9) && H == 15 && W == 15 && C % CG == 0 && ac_aligned16(x) && B * (C / CG) >= 256)
+        return variant == 8 ? launch_pipe_fwd<15, 8, 1>(x, w, bias, y, B, C, stream)
+                            : launch_pipe_fwd<15, 8, 2>(x, w, bias, y, B, C, stream);
     if (variant != 1 && H == W && (W == 15 || W == 7) && C % CG == 0 && ac_aligned16(x) && B * (C / CG) >= 256)
-        return W == 15 ? launch_pipe_fwd<15, 8>(x, w, bias, y, B, C, stream) : launch_pipe_fwd<7, 8>(x, w, bias, y, B, C, stream);
+        return W == 15 ? (variant == 7 ? launch_pipe_fwd<15, 8>(x, w, bias, y, B, C, stream)
+                                       : launch_pipe_fwd<15, 16>(x, w, bias, y, B, C, stream))
+                       : launch_pipe_fwd<7, 8>(x, w, bias, y, B, C, stream);
     if (H == W && (W == 1 || W == 3)) {
         const int spb = small_spb(B);
         dim3 grid((C + 63) / 64, (B + spb - 1) / spb);
