@@ -797,10 +797,11 @@ def main():
                                          ceilings.get("mfma_bf16_16x16x32_2wave_per_simd_TFLOPs", peak)), 4)
     if other is not None:
         out["roofline_other_class"] = other
+    pending_rocprof = {}
     if "dwconv7x7_fwd" in ks:
         d = ks["dwconv7x7_fwd"]
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9   # from the single-stream roofline pass
-        out["roofline_hbm"] = {"bound": "hbm", "kernel": "dwconv7x7_fwd_kernel (15x15x96 stage)", "achieved": round(gbs, 1),
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": "depthwise 7x7 forward, 15x15x96 stage (dwconv_pipe_fwd_kernel)", "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "traffic": None, "launches": d["launches"],
                                "measured": "HIP-event bracket around each launch (includes the launch gap of a ~28 us kernel)"}
@@ -811,14 +812,18 @@ def main():
             if not os.path.exists(stats):
                 stats = os.path.join(ROOT, "profiles", "r02_bench_%s_kernel_stats_%s_single_stream.csv"
                                      % (args.math, "v4" if args.math == "bf16x3" else "v3"))
-            for row in csv.DictReader(open(stats)):
-                if "dwconv_rows_fwd_kernelILi15" in row["Name"]:
-                    us = float(row["AverageNs"]) / 1e3
-                    per_launch = d["bytes"] / d["launches"]
-                    out["roofline_hbm"]["rocprof_avg_us"] = round(us, 2)
-                    out["roofline_hbm"]["frac_rocprof"] = round(per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                    out["roofline_hbm"]["rocprof_source"] = "profiles/" + os.path.basename(stats) + " (NOT measured in this run)"
-                    break
+            rows = list(csv.DictReader(open(stats)))
+            for key, tags in (("roofline_hbm", ("dwconv_pipe_fwd_kernelILi15", "dwconv_rows_fwd_kernelILi15")),
+                              ("roofline_hbm_bwd", ("dwconv_pipe_bwd_kernelILi15", "dwconv_rows_bwd_kernelILi15"))):
+                src = ks.get("dwconv7x7_fwd" if key == "roofline_hbm" else "dwconv7x7_bwd")
+                hit = [r for r in rows if any(t in r["Name"] for t in tags)]
+                if src and hit:
+                    us = float(hit[0]["AverageNs"]) / 1e3
+                    pending_rocprof[key] = {"rocprof_avg_us": round(us, 2),
+                                            "frac_rocprof": round(src["bytes"] / src["launches"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "rocprof_source": "profiles/" + os.path.basename(stats) + " (same command under "
+                                                              "rocprofv3 --kernel-trace; NOT measured in this run)"}
+            out["roofline_hbm"].update(pending_rocprof.get("roofline_hbm", {}))
         except Exception:
             pass
     if "dwconv7x7_bwd" in ks:
@@ -829,6 +834,7 @@ def main():
                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": d["launches"],
                                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                                    "measured": "HIP-event bracket around each launch (x, dy read once, dx written once)"}
+        out["roofline_hbm_bwd"].update(pending_rocprof.get("roofline_hbm_bwd", {}))
         if ceilings and "copy_GBps" in ceilings:
             out["roofline_hbm_bwd"]["frac_of_measured_ceiling"] = round(gbs / ceilings["copy_GBps"], 4)
     if "roofline_hbm" in out and ceilings and "copy_GBps" in ceilings:
