@@ -165,7 +165,7 @@ SIGNATURES = {
     "ac_ceil_copy": [_P, _P, _I64, _P],
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 _RESTYPES = {"ac_strerror": C.c_char_p}
 
 _lib = None

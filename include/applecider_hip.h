@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AC_ABI_VERSION 2
+#define AC_ABI_VERSION 3
 
 #define AC_OK 0
 #define AC_EINVAL (-22)     /* bad argument / unsupported shape            */
