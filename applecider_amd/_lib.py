@@ -57,7 +57,8 @@ class ConvWinDesc(C.Structure):
                 ("w", C.c_void_p), ("w_row_stride", C.c_int64), ("w_tap_stride", C.c_int64),
                 ("flip", C.c_int32), ("N", C.c_int32), ("c", C.c_void_p), ("ldc", C.c_int64),
                 ("bias", C.c_void_p), ("accumulate", C.c_int32), ("variant", C.c_int32),
-                ("c16", C.c_void_p), ("ldc16", C.c_int64), ("a_lo_off", C.c_int64), ("w_lo_off", C.c_int64)]
+                ("c16", C.c_void_p), ("ldc16", C.c_int64), ("a_lo_off", C.c_int64), ("w_lo_off", C.c_int64),
+                ("tap_row_step", C.c_int32), ("c_block", C.c_int32), ("c_block_stride", C.c_int64)]
 
 
 class WgradDesc(C.Structure):

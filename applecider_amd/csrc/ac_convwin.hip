@@ -839,7 +839,8 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *win_h = reinterpret_cast<unsigned short *>(smem);
     const ac_convwin_desc &d = p.d;
-    const int Wrows = (d.L < BM ? (BM / d.L) * (d.L + TC - 1) : BM + TC - 1);
+    const int tstep = d.tap_row_step > 1 ? d.tap_row_step : 1;   // window rows per tap (8: Toeplitz form, see the header)
+    const int Wrows = (d.L < BM ? (BM / d.L) * (d.L + tstep * (TC - 1)) : BM + tstep * (TC - 1));
     unsigned short *win_l = win_h + Wrows * CC;
     const int t = threadIdx.x, lane = t & 63;
     const int grp = (t >> 6) / NWG, wave = (t >> 6) % NWG;
@@ -883,9 +884,9 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
         for (int t0 = 0; t0 < d.k; t0 += TC) {
             const int tc = (d.k - t0) < TC ? (d.k - t0) : TC;
             __syncthreads();   // previous chunk: window and ring idle, every DMA drained
-            const int wr = Ls + tc - 1;
+            const int wr = Ls + tstep * (tc - 1);
             {
-                const unsigned short *a = aptr + (int64_t)t0 * d.a_row_stride + cch * CC;
+                const unsigned short *a = aptr + (int64_t)t0 * tstep * d.a_row_stride + cch * CC;
                 for (int idx = t; idx < spt * wr * 8; idx += NT) {
                     const int rr_ = idx >> 3, cc = idx & 7;
                     const int sidx = spt > 1 ? rr_ / wr : 0, r = rr_ - sidx * wr;
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
                 }
             };
             auto ldA = [&](int jj, int h, bf16x8 (&A)[4]) {
-                const int to = tapl(jj), cc = 4 * (jj & 1) + g;
+                const int to = tstep * tapl(jj), cc = 4 * (jj & 1) + g;
                 if constexpr (SHORT) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -1023,6 +1024,8 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
     float *wbuf = smem + wave * (GR == 2 ? 4096 : 2048);
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = tn * BN + wn * 64 + c4;
+    // column n -> offset inside an output row (plain, or blocks of c_block columns c_block_stride apart)
+    const int64_t ncol = d.c_block > 0 ? (int64_t)(n / d.c_block) * d.c_block_stride + n % d.c_block : n;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (d.bias && n < d.N && blockIdx.y == 0) bias4 = *(const f32x4 *)(d.bias + n);
 #pragma unroll
@@ -1040,7 +1043,7 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
             f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4) + bias4;
             if (n < d.N) {
                 const int64_t row = wm * 64 + sa * 32 + r;
-                f32x4 *dst = (f32x4 *)(cb + row * d.ldc + n);
+                f32x4 *dst = (f32x4 *)(cb + row * d.ldc + ncol);
                 if (csplit > 1) {
                     float *df = (float *)dst;
                     atomicAdd(df, v[0]);
@@ -1110,10 +1113,11 @@ int launch_x3r(ConvWinParams &p, hipStream_t stream) {
     const size_t stages = (size_t)GR * NS * 2 * BN * 32 * sizeof(short);   // ring of NS half-stages per group
     const int rows_budget = (int)((160 * 1024 - stages) / (2 * 64 * sizeof(short)));
     const int spt = d.L < BM ? BM / d.L : 1, Ls = d.L < BM ? d.L : BM;
-    int TC = rows_budget / spt - Ls + 1;
+    const int tstep = d.tap_row_step > 1 ? d.tap_row_step : 1;
+    int TC = (rows_budget / spt - Ls) / tstep + 1;
     if (TC < 1) return AC_EINVAL;
     if (TC > d.k) TC = d.k;
-    const size_t lds = (size_t)spt * (Ls + TC - 1) * 64 * 2 * sizeof(short) + stages;
+    const size_t lds = (size_t)spt * (Ls + tstep * (TC - 1)) * 64 * 2 * sizeof(short) + stages;
     if (lds < (size_t)WM * WN * (GR == 2 ? 16384 : 8192)) return AC_EINVAL;
     p.tiles_l = d.L / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
@@ -1129,7 +1133,7 @@ int launch_x3r(ConvWinParams &p, hipStream_t stream) {
     const int row_tiles = (int)(((int64_t)d.B * d.L) / BM);
     int csplit = 1;
     const int wgs = row_tiles * p.tiles_n, cchunks = d.C / 64;
-    if (wgs <= 128 && cchunks >= 4 && d.ldc == d.N) {
+    if (wgs <= 128 && cchunks >= 4 && d.ldc == d.N && d.c_block == 0) {
         csplit = 256 / wgs;
         if (csplit > cchunks / 2) csplit = cchunks / 2;
         if (csplit > 4) csplit = 4;
@@ -1186,6 +1190,11 @@ extern "C" int ac_conv1d_window_x3(const ac_convwin_desc *dp, ac_stream_t stream
     const bool wide = d.N > 64;
     // N <= 64: one column of waves only -> a second wave group on the odd taps (needs a few taps to share)
     const bool two = !wide && d.k >= 4;
+    const bool extended = d.tap_row_step > 1 || d.c_block > 0;   // Toeplitz form / blocked output columns: ring kernel only
+    if (d.tap_row_step < 0 || d.c_block < 0 || (d.c_block > 0 && ((d.c_block % 4) || (d.c_block_stride % 4))))
+        return AC_EINVAL;
+    if (extended && !((d.variant == 0 || d.variant == 5) && (d.L % 256 == 0 || short_seq) && (wide || two)))
+        return AC_EINVAL;
     // default (variant 0 / 5): the ring kernel (weights by LDS-DMA into four half-stages, fragments prefetched across
     // the barrier); 6 = the same with a fifth half-stage; 4 = the round-2 kernel (two register-staged stages),
     // 2 / 3 = its 32x32x16 / one-group forms (A/B measurements, tests)

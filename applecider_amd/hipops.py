@@ -240,7 +240,8 @@ _X3_VARIANT = 0   # 0: v_mfma_f32_16x16x32 form (default) ; 2: the 32x32x16 form
 
 
 def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, w_planes,
-                   w_row_stride, w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate) -> bool:
+                   w_row_stride, w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate, tap_row_step=0, c_block=0,
+                   c_block_stride=0) -> bool:
     """Split-bf16 conv through the LDS-resident-window kernel: three passes over (hi, lo) operand
     planes — hi*hi (+bias), lo*hi, hi*lo — accumulating in the fp32 output.  False when the shape is
     not covered (nothing has been written then)."""
@@ -258,11 +259,14 @@ def conv_window_x3(a_planes, a_batch_stride, a_row_stride, a_col_off, row_base, 
         d.a_lo_off = (al.data_ptr() - ah.data_ptr()) // 2
         d.w_lo_off = (wl.data_ptr() - wh.data_ptr()) // 2
         d.variant = _X3_VARIANT
+        d.tap_row_step, d.c_block, d.c_block_stride = int(tap_row_step), int(c_block), int(c_block_stride)
         rc = _lib_().ac_conv1d_window_x3(C.byref(d), _stream())
         if rc == 0:
             return True
         if rc != _lib.AC_EINVAL:
             _lib.check(rc, "ac_conv1d_window_x3")
+    if tap_row_step or c_block:
+        return False    # the Toeplitz / blocked-column form exists on the ring kernel only
     if not conv_window(ah, a_batch_stride, a_row_stride, a_col_off, row_base, B, L, Cw, k, wh, w_row_stride,
                        w_tap_stride, flip, N, c_ptr, ldc, bias, accumulate):
         return False
@@ -407,6 +411,7 @@ def _big(M, N, K) -> bool:
 
 
 _CONVWIN = True
+_TOEPLITZ_RING = True   # split-bf16: the Cin = 1 conv bank's forward on the ring window kernel (tests switch it)
 _LN_PLANES = True   # split-bf16: LayerNorm backward emits the (hi, lo) planes of d(conv outputs) (tests switch it)
 
 
@@ -1658,20 +1663,43 @@ class _ConvGroup1d(Function):
                 raise ValueError("Cin == 1 path needs L % 8 == 0")
             al = 8 if b16 else 4  # 16-byte granules in operand elements
             Lp = (L + 2 * Pmax + 48 + 7) // 8 * 8
-            xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, 1, Pmax, Lp)
             Lq = L // 8
+            # split-bf16 mode: the Toeplitz products run on the ring window kernel (weights by LDS-DMA, fragments
+            # prefetched across the barrier) over (hi, lo) planes of the padded flux: "taps" of 64 window elements,
+            # window rows 8 elements apart (ac_convwin_desc.tap_row_step = 8) — 296 -> ~530 TFLOP/s on the k = 1021
+            # product.  K is padded to 64, so the zero tail of the padded flux grows by up to 63 + 7 elements.
+            toep = bool(not b16 and x3_mode() and _CONVWIN and _CONVWIN_X3_FUSED and _TOEPLITZ_RING and Cout % 8 == 0
+                        and (Lq % 256 == 0 or (Lq < 128 and Lq >= 8 and (Lq & (Lq - 1)) == 0 and (B * Lq) % 256 == 0)))
+            if toep:
+                kp_max = max((k + 7 + (Pmax - k // 2) % 8 + 63) // 64 * 64 for k in ksizes)
+                Lp = max(Lp, (L + Pmax + kp_max + 8 + 7) // 8 * 8)
+            xpad = (_pad_rows16 if b16 else _pad_rows)(x, B, L, 1, Pmax, Lp)
+            xpl = split16(xpad) if toep else None
             saved_meta = []
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 shift = off % al
                 base = off - shift
                 Kp = (k + 7 + shift + al - 1) // al * al
-                wexp = torch.empty(8 * Cout, Kp, device=dev, dtype=torch.float32)
-                _lib.check(_lib_().ac_toeplitz_expand(_p(ws[j]), _p(wexp), Cout, k, Kp, shift,
-                                                      _stream()), "ac_toeplitz_expand")
                 goff_c = _table(("tz", Ncat, Cout, j),
                                 lambda j=j: [r * Ncat + j * Cout + cb * 32 for r in range(8)
                                              for cb in range(Cout // 32)], dev)
+                if toep:
+                    shift8 = off % 8
+                    Kp64 = (k + 7 + shift8 + 63) // 64 * 64
+                    wexp8 = torch.empty(8 * Cout, Kp64, device=dev, dtype=torch.float32)
+                    _lib.check(_lib_().ac_toeplitz_expand(_p(ws[j]), _p(wexp8), Cout, k, Kp64, shift8, _stream()),
+                               "ac_toeplitz_expand")
+                    bexp = bs[j].detach().repeat(8) if bs[j] is not None else None
+                    done = conv_window_x3(xpl, Lp, 8, off - shift8, 0, B, Lq, 64, Kp64 // 64, split16(wexp8), Kp64, 64,
+                                          False, 8 * Cout, _p(ycat, j * Cout), 8 * Ncat, bexp, False,
+                                          tap_row_step=8, c_block=Cout, c_block_stride=Ncat)
+                    if done:
+                        saved_meta.append((base, shift, Kp, goff_c))
+                        continue
+                wexp = torch.empty(8 * Cout, Kp, device=dev, dtype=torch.float32)
+                _lib.check(_lib_().ac_toeplitz_expand(_p(ws[j]), _p(wexp), Cout, k, Kp, shift,
+                                                      _stream()), "ac_toeplitz_expand")
                 # bias[(r,co)] = b[co]; 8*Cout floats of plumbing
                 bexp = bs[j].detach().repeat(8) if bs[j] is not None else None
                 wop = cast16(wexp) if b16 else wexp

@@ -110,19 +110,21 @@ class KernelTimer:
         PRODUCT with its algorithmic FLOP (2 B L N k C) and bytes (both planes of A and W once, fp32 out)."""
         orig = H.conv_window_x3
 
-        def timed(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+        def timed(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
             if not self.enabled:
-                return orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+                return orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self._suppress = True
             try:
                 s.record()
-                ok = orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+                ok = orig(ap, abs_, ars, aco, rb, B, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
                 e.record()
             finally:
                 self._suppress = False
             if ok:
-                byts = 4.0 * B * (L + k - 1) * Cw + 4.0 * N * k * Cw + 4.0 * (2 if acc else 1) * B * L * N
+                # (Toeplitz form, tap_row_step = 8: the A operand is ONE sequence of 8 L + 64 k elements per sample)
+                a_elems = (8.0 * L + 64.0 * k) if kw.get("tap_row_step") else float(L + k - 1) * Cw
+                byts = 4.0 * B * a_elems + 4.0 * N * k * Cw + 4.0 * (2 if acc else 1) * B * L * N
                 self.records.setdefault("conv1d_window", []).append((s, e, 2.0 * B * L * N * k * Cw, byts))
             return ok
         H.conv_window_x3 = timed

@@ -186,6 +186,15 @@ typedef struct ac_convwin_desc {
     int64_t ldc16;
     int64_t a_lo_off, w_lo_off; /* ac_conv1d_window_x3 only: element offsets from the hi plane of A / W
                                    to its lo plane (split-bf16 operands, math mode bf16x3) */
+    /* ac_conv1d_window_x3, ring kernel only (0 = plain conv).  tap_row_step > 1: tap t reads window rows
+     * (l + tap_row_step * t); with a_row_stride = 8, C = 64 and tap_row_step = 8 the "window rows" are overlapping
+     * 64-element views of ONE sequence and the product is the Toeplitz form of a Cin = 1 convolution (SpectraNet
+     * stage 1, spectranet.py:18-20 with in_channels = 1): row = 8 consecutive output positions, column n =
+     * (position p, channel co), K = the k + 7 window in 64-element "taps".  c_block > 0: output column n lands at
+     * c[row * ldc + (n / c_block) * c_block_stride + n % c_block] — the 8 positions of a Toeplitz row are 8
+     * rows of the channels-last output (c_block = Cout, c_block_stride = its row pitch, ldc = 8 * that). */
+    int32_t tap_row_step, c_block;
+    int64_t c_block_stride;
 } ac_convwin_desc;
 int ac_conv1d_window_bf16(const ac_convwin_desc *d, ac_stream_t stream);
 /* The same product on split-bf16 operands in one launch: 3 MFMAs per fragment pair, the K loop cut

@@ -339,3 +339,40 @@ def test_conv_bank_layernorm_backward_writes_the_operand_planes(dev, math_mode, 
     for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
         assert rel(a, b_) <= 2e-6, (i, rel(a, b_))
         assert rel(a, w_) <= 1e-4, (i, rel(a, w_))
+
+
+@pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
+@pytest.mark.parametrize("B,L,Cout,ks", [(2, 4096, 64, (3, 61, 1021)), (1, 2048, 32, (3, 15, 61)), (4, 2048, 64, (5, 251))])
+def test_conv_bank_cin1_toeplitz_on_the_ring_kernel(dev, math_mode, B, L, Cout, ks):
+    """SpectraNet stage 1 (in_channels = 1, k up to 1021: spectranet.py:18-20, default_config.toml:104-114) in
+    split-bf16 mode: the Toeplitz products on the ring window kernel over (hi, lo) planes of the padded flux (64-element
+    'taps', window rows 8 apart, blocked output columns) against torch conv1d in fp64 and against the gather-GEMM
+    form; the backward (unchanged) still sees consistent saved state."""
+    import math
+    import torch.nn.functional as F
+    from applecider_amd import hipops as H
+    gen = torch.Generator().manual_seed(L + Cout)
+    x = torch.randn(B, 1, L, generator=gen, dtype=torch.float64)
+    ws = [(torch.randn(Cout, 1, k, generator=gen, dtype=torch.float64) / math.sqrt(k)).requires_grad_() for k in ks]
+    bs = [torch.randn(Cout, generator=gen, dtype=torch.float64).requires_grad_() for _ in ks]
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    go = torch.randn(*y.shape, generator=gen, dtype=torch.float64)
+    y.backward(go)
+    res = {}
+    for ring in (True, False):
+        H._TOEPLITZ_RING = ring
+        try:
+            xd = x.float().permute(0, 2, 1).contiguous().to(dev)
+            wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+            bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
+            yd = H.conv_group1d(xd, ks, wd, bd)
+            yd.backward(go.float().permute(0, 2, 1).contiguous().to(dev))
+            torch.cuda.synchronize()
+        finally:
+            H._TOEPLITZ_RING = True
+        res[ring] = [yd.detach()] + [w.grad for w in wd] + [b.grad for b in bd]
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+    want = [y.detach().permute(0, 2, 1)] + [w.grad.permute(0, 2, 1).reshape(Cout, -1) for w in ws] + [b.grad for b in bs]
+    for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
+        assert rel(a, w_) <= 5e-5, (i, rel(a, w_))
+        assert rel(a, b_) <= 2e-5, (i, rel(a, b_))

@@ -22,10 +22,10 @@ records = {}
 orig = H.conv_window_x3
 
 
-def timed(ap, abs_, ars, aco, rb, B_, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+def timed(ap, abs_, ars, aco, rb, B_, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    ok = orig(ap, abs_, ars, aco, rb, B_, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+    ok = orig(ap, abs_, ars, aco, rb, B_, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
     e.record()
     records.setdefault((L, Cw, k, N, bool(flip), H._X3_VARIANT), []).append((s, e, 2.0 * B_ * L * N * k * Cw))
     return ok

@@ -63,15 +63,15 @@ owx = H.conv_window_x3
 sup = [False]
 
 
-def twx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc):
+def twx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw):
     if not on[0]:
-        return owx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc)
+        return owx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     on[0] = False   # inner conv_window launches (3-pass fallback) are part of this record
-    s.record(); ok = owx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc); e.record()
+    s.record(); ok = owx(ap, abs_, ars, aco, rb, Bn, L, Cw, k, wp, wrs, wts, flip, N, c_ptr, ldc, bias, acc, **kw); e.record()
     on[0] = True
     if ok:
-        recs.setdefault(("WX3", Bn * L, N, k * Cw, "f" if flip else "-", 1), []).append((s, e, 2.0 * Bn * L * N * k * Cw))
+        recs.setdefault(("WX3", Bn * L, N, k * Cw, "t" if kw.get("tap_row_step") else ("f" if flip else "-"), 1), []).append((s, e, 2.0 * Bn * L * N * k * Cw))
     return ok
 
 
