@@ -68,7 +68,8 @@ class WgradDesc(C.Structure):
                 ("x_row_base", C.c_int32), ("x_rows", C.c_int32),
                 ("B", C.c_int32), ("L", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32), ("k", C.c_int32),
                 ("split_k", C.c_int32), ("dw", C.c_void_p), ("ldw", C.c_int64),
-                ("dy_lo_off", C.c_int64), ("x_lo_off", C.c_int64), ("variant", C.c_int32)]
+                ("dy_lo_off", C.c_int64), ("x_lo_off", C.c_int64), ("variant", C.c_int32),
+                ("tap_row_step", C.c_int32), ("dy_block", C.c_int32), ("dy_block_stride", C.c_int64)]
 
 
 class TowerDesc(C.Structure):

@@ -28,13 +28,15 @@ constexpr int WG_TAPS = 8, WG_KP = 64, WG_CO = 128, WG_CI = 64;
 // window rows: 64 positions + 8 taps of one sample; short sequences (L = 16 / 32: SpectraNet stages 4-5 have
 // L = 64 / 16) put 64 / L whole samples in a K step, each with its own L + 8 rows -> at most 4 x 24 = 96
 constexpr int B_ROWS = 96;
+// Toeplitz form (ac_wgrad_desc.tap_row_step = 8): tap t reads window rows (position + 8 t): 64 + 8 * 8 rows
+constexpr int B_ROWS_TOEP = 128, TOEP_STEP = 8;
 // Row pitches (elements) by MFMA shape.  32x32x16 form: a 32-lane half reads 4 rows x 64 bytes, pitch = 16
 // banks (mod 64).  16x16x32 form: a half reads 8 consecutive rows x 32 bytes, pitch = an odd multiple of
 // 8 banks.  Both conflict-free for ds_read_b64_tr_b16.
-template <bool S16> struct Img {
+template <bool S16, bool TOEP = false> struct Img {
     static constexpr int A_PITCH = S16 ? WG_CO + 16 : WG_CO + 32;
     static constexpr int B_PITCH = S16 ? WG_CI + 16 : WG_CI + 32;
-    static constexpr int A_IMG = WG_KP * A_PITCH, B_IMG = B_ROWS * B_PITCH;
+    static constexpr int A_IMG = WG_KP * A_PITCH, B_IMG = (TOEP ? B_ROWS_TOEP : B_ROWS) * B_PITCH;
 };
 
 struct WgradParams {
@@ -81,12 +83,14 @@ __device__ __forceinline__ bf16x8 frag16_t(const unsigned short *img, int colbas
 
 // SHORT: L = 16 / 32 (64 / L whole samples per K step); a separate instantiation so that the long-sequence
 // kernel keeps its compile-time addressing (as one runtime-switched kernel it lost 18 %).
-template <bool SPLIT, bool S16, bool SHORT>
+// TOEP: the Toeplitz form (header: ac_wgrad_desc.tap_row_step) — window rows 8 per tap, blocked dy columns
+template <bool SPLIT, bool S16, bool SHORT, bool TOEP = false>
 __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
     const ac_wgrad_desc &d = p.d;
-    constexpr int A_PITCH = Img<S16>::A_PITCH, B_PITCH = Img<S16>::B_PITCH;
-    constexpr int A_IMG = Img<S16>::A_IMG, B_IMG = Img<S16>::B_IMG;
+    constexpr int A_PITCH = Img<S16, TOEP>::A_PITCH, B_PITCH = Img<S16, TOEP>::B_PITCH;
+    constexpr int A_IMG = Img<S16, TOEP>::A_IMG, B_IMG = Img<S16, TOEP>::B_IMG;
+    constexpr int TSTEP = TOEP ? TOEP_STEP : 1;
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = NPL * (A_IMG + B_IMG);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
     const int steps_per_seq = shortL ? 1 : d.L / WG_KP;
     const int lsh = shortL ? 31 - __builtin_clz(d.L) : 6;  // log2 of the positions per sample in a step
     const int seg = shortL ? d.L + WG_TAPS : 0;           // window rows per sample (short sequences)
-    const int nbrow = shortL ? (WG_KP >> lsh) * seg : WG_KP + WG_TAPS;
+    const int nbrow = shortL ? (WG_KP >> lsh) * seg : WG_KP + TSTEP * WG_TAPS;
 
     auto gload_step = [&](int step, u32x4 (&ra)[2 * NPL], u32x4 (&rb)[2 * NPL]) {
         int b, l0;
@@ -139,7 +143,9 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
             ao0 = (int64_t)(d.dy_row_base + l0 + ar) * d.dy_row_stride;
             ao1 = ao0 + 32 * d.dy_row_stride;
         }
-        const unsigned short *ap = dy + (int64_t)b * d.dy_batch_stride + d.dy_col_off + cot * WG_CO + ac * 8;
+        int acol = cot * WG_CO + ac * 8;   // column of the dy row; blocked layout: (c / block) * stride + c % block
+        if constexpr (TOEP) acol = (acol / d.dy_block) * (int)d.dy_block_stride + acol % d.dy_block;
+        const unsigned short *ap = dy + (int64_t)b * d.dy_batch_stride + d.dy_col_off + acol;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
             ra[2 * pl] = ac_gload<u32x4>(ap + pl * d.dy_lo_off + ao0);
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
             s0 = w0 / seg; w0 -= s0 * seg;
             s1 = w1 / seg; w1 -= s1 * seg;
         }
-        int row0 = d.x_row_base + l0 + t0 + w0;
-        int row1 = d.x_row_base + l0 + t0 + w1;
+        int row0 = d.x_row_base + l0 + TSTEP * t0 + w0;
+        int row1 = d.x_row_base + l0 + TSTEP * t0 + w1;
         row0 = row0 < d.x_rows ? row0 : d.x_rows - 1;
         row1 = row1 < d.x_rows ? row1 : d.x_rows - 1;
         const unsigned short *bp = x + (int64_t)b * d.x_batch_stride + cit * WG_CI + bc * 8;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
                 bf16x8 b_h[4], b_l[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    b_h[j] = frag16_t<B_PITCH, SHORT>(bh + tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
-                    if (SPLIT) b_l[j] = frag16_t<B_PITCH, SHORT>(bl + tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
+                    b_h[j] = frag16_t<B_PITCH, SHORT>(bh + TSTEP * tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
+                    if (SPLIT) b_l[j] = frag16_t<B_PITCH, SHORT>(bl + TSTEP * tap * B_PITCH, 16 * j, s2, lane, krow[s2]);
                 }
                 if (SPLIT) {
 #pragma unroll
@@ -323,16 +329,17 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
 // re-streamed every step here (26 DMA instructions per half against 16 in the window kernel, each ~60-100 issue
 // cycles of a wave that then feeds the matrix pipe nothing), the barrier interval halves, and the input rows' halo
 // is fetched twice; this kernel's 192 MFMAs per wave and barrier already hide most of what the ring removes.
-template <bool SPLIT, bool S16, bool SHORT = false>
+template <bool SPLIT, bool S16, bool SHORT = false, bool TOEP = false>
 int launch_wgrad(WgradParams &p, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
-    constexpr size_t LDS = (size_t)2 * NPL * (Img<S16>::A_IMG + Img<S16>::B_IMG) * sizeof(short);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT, S16, SHORT>,
+    constexpr size_t LDS = (size_t)2 * NPL * (Img<S16, TOEP>::A_IMG + Img<S16, TOEP>::B_IMG) * sizeof(short);
+    static_assert(LDS <= 160 * 1024, "two stages in the LDS");
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv1d_wgrad_kernel<SPLIT, S16, SHORT, TOEP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (attr != hipSuccess) return -(int)attr - 2000;
     const ac_wgrad_desc &d = p.d;
     dim3 grid(p.co_tiles * p.ci_tiles * p.tap_chunks * ((p.steps_total + p.steps_per_split - 1) / p.steps_per_split));
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT, S16, SHORT>), grid, dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<SPLIT, S16, SHORT, TOEP>), grid, dim3(512), LDS, stream, p);
     AC_CHECK_LAUNCH();
     (void)d;
     return AC_OK;
@@ -363,6 +370,12 @@ extern "C" int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *dp, ac_stream_t stream)
     p.steps_per_split = (p.steps_total + split - 1) / split;
     const bool sp = d.dy_lo_off != 0 || d.x_lo_off != 0;
     if (sp && (d.dy_lo_off == 0 || d.x_lo_off == 0)) return AC_EINVAL;
+    if (d.tap_row_step > 1 || d.dy_block > 0) {   // Toeplitz form: split-bf16, 16x16x32 tiles, long sequences
+        if (d.tap_row_step != TOEP_STEP || d.dy_block <= 0 || (d.dy_block % 8) || (d.dy_block_stride % 8) || !sp || short_seq ||
+            d.Cin != WG_CI || d.variant == 2)
+            return AC_EINVAL;
+        return launch_wgrad<true, true, false, true>(p, (hipStream_t)stream);
+    }
     // variant 2: the 32x32x16 form (A/B measurements); default: v_mfma_f32_16x16x32 (higher sustained clock)
     if (d.variant == 2)
         return sp ? launch_wgrad<true, false>(p, (hipStream_t)stream) : launch_wgrad<false, false>(p, (hipStream_t)stream);

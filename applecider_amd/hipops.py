@@ -472,7 +472,8 @@ _WGRAD_WIN = True   # tests switch the LDS-window weight-gradient kernel off to 
 
 
 def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_off, x, x_lo, x_batch_stride,
-               x_row_stride, x_row_base, x_rows, B, L, Cout, Cin, k, dw) -> bool:
+               x_row_stride, x_row_base, x_rows, B, L, Cout, Cin, k, dw, tap_row_step=0, dy_block=0, dy_block_stride=0,
+               x_elem_off=0, ldw=None) -> bool:
     """dw[Cout, k*Cin] += conv weight gradient through the LDS-window kernel (ac_conv1d_wgrad_bf16).
     dy / x are bf16 tensors (dy_lo / x_lo: the lo planes in split-bf16 mode, else None).  False when
     the shape is not covered (the caller then runs the generic TN product)."""
@@ -485,13 +486,14 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     d = _lib.WgradDesc()
     d.dy, d.dy_batch_stride, d.dy_row_stride = _p(dy), dy_batch_stride, dy_row_stride
     d.dy_row_base, d.dy_col_off = dy_row_base, dy_col_off
-    d.x, d.x_batch_stride, d.x_row_stride = _p(x), x_batch_stride, x_row_stride
+    d.x, d.x_batch_stride, d.x_row_stride = _p(x, x_elem_off), x_batch_stride, x_row_stride
     d.x_row_base, d.x_rows = x_row_base, x_rows
     d.B, d.L, d.Cout, d.Cin, d.k = B, L, Cout, Cin, k
+    d.tap_row_step, d.dy_block, d.dy_block_stride = int(tap_row_step), int(dy_block), int(dy_block_stride)
     tiles = (Cout // 128) * (Cin // 64) * (-(-k // 8))
     steps = (B * L) // 64
     d.split_k = max(1, min(steps // 16, -(-512 // tiles)))
-    d.dw, d.ldw = _p(dw), k * Cin
+    d.dw, d.ldw = _p(dw), (k * Cin if ldw is None else ldw)
     d.variant = _X3_VARIANT
     d.dy_lo_off = (dy_lo.data_ptr() - dy.data_ptr()) // 2 if dy_lo is not None else 0
     d.x_lo_off = (x_lo.data_ptr() - x.data_ptr()) // 2 if x_lo is not None else 0
@@ -1715,6 +1717,7 @@ class _ConvGroup1d(Function):
                 saved_meta.append((base, shift, Kp, goff_c))
             ctx.meta = saved_meta
             ctx.Lp = Lp
+            ctx.xpl = xpl      # (hi, lo) planes of the padded flux: the Toeplitz weight-gradient products read them too
         else:
             if Cin % 32:
                 raise ValueError("ConvGroup1d needs Cin == 1 or Cin % 32 == 0")
@@ -1794,7 +1797,7 @@ class _ConvGroup1d(Function):
         need_dx = Cin != 1 and ctx.needs_input_grad[0]
         Lpd = L + 2 * Pmax
         dypad = dyop = None
-        planes_direct, ctx_dyplanes = False, None
+        planes_direct, ctx_dyplanes, dy1planes = False, None, None
         if ctx.fused_ln:
             saved = ctx.saved_tensors
             xpad, ws = saved[0], list(saved[1:1 + nconv])
@@ -1817,7 +1820,16 @@ class _ConvGroup1d(Function):
                              and getattr(ctx, "xplanes", None) is not None and dy16in is None and not ctx.cat16
                              and _x3_bank_covered(B, L, Cin, Cout))
             lo16 = None
-            if planes_direct:
+            # stage 1 (Cin = 1): its three Toeplitz weight-gradient products read (hi, lo) planes of d(ycat) too, and
+            # nothing else reads the fp32 form (no input gradient, bias sums come out of this pass)
+            planes1 = bool(_LN_PLANES and not b16 and x3_mode() and Cin == 1 and fuse_bias and _ln_sub_shape(Ncat)
+                           and getattr(ctx, "xpl", None) is not None and dy16in is None and not ctx.cat16
+                           and _WGRAD_WIN and _TOEPLITZ_RING and Cout % 16 == 0 and (L // 8) % 64 == 0 and Ncat % 8 == 0)
+            if planes1:
+                both = torch.empty(2, B * L, Ncat, device=dev, dtype=_H16)
+                out16, lo16 = both[0], both[1]
+                dy1planes = (both[0], both[1])
+            elif planes_direct:
                 both = torch.empty(2, B, Lpd, Ncat, device=dev, dtype=_H16)
                 if Pmax > 0:
                     both[:, :, :Pmax].zero_()
@@ -1873,8 +1885,35 @@ class _ConvGroup1d(Function):
             dy_mat = lambda j: mat(_p(dyop, j * Cout), Ncat)
         if Cin == 1:
             Lq = L // 8
+            xpl = getattr(ctx, "xpl", None)
+            # split-bf16: the Toeplitz weight gradients on the LDS-window weight-gradient kernel (its Toeplitz form:
+            # 64-element "taps", window rows 8 apart, blocked dy columns) over the planes of d(ycat) and of the flux
+            toepw = bool(xpl is not None and _WGRAD_WIN and _TOEPLITZ_RING and Cout % 16 == 0 and Lq % 64 == 0
+                         and Ncat % 8 == 0)
+            dyp = None
+            if toepw:
+                dyp = dy1planes if dy1planes is not None else split16(dycat.reshape(B * L, Ncat))
             for j, k in enumerate(ksizes):
                 base, shift, Kp, goff_c = ctx.meta[j]
+                if toepw:
+                    off = Pmax - k // 2
+                    shift8 = off % 8
+                    Kp64 = (k + 7 + shift8 + 63) // 64 * 64
+                    dwexp8 = torch.zeros(8 * Cout, Kp64, device=dev, dtype=torch.float32)
+                    xoff = off - shift8
+                    if conv_wgrad(dyp[0], dyp[1], L * Ncat, 8 * Ncat, 0, j * Cout, xpl[0], xpl[1], Lp, 8, 0,
+                                  (Lp - xoff - 64) // 8 + 1, B, Lq, 8 * Cout, 64, Kp64 // 64, dwexp8, tap_row_step=8,
+                                  dy_block=Cout, dy_block_stride=Ncat, x_elem_off=xoff, ldw=Kp64):
+                        dw = torch.empty(Cout, k, device=dev, dtype=torch.float32)
+                        _lib.check(_lib_().ac_toeplitz_fold(_p(dwexp8), _p(dw), Cout, k, Kp64, shift8, _stream()),
+                                   "ac_toeplitz_fold")
+                        grads += [dw, bias_grad(j)]
+                        continue
+                    if dycat is None:
+                        raise RuntimeError("split-bf16 Cin = 1 conv bank: the Toeplitz weight-gradient kernel refused "
+                                           "a shape its dispatch admits")
+                if dyop is None:
+                    dyop = dycat
                 dwexp = torch.zeros(8 * Cout, Kp, device=dev, dtype=torch.float32)
                 gemm(AC_GEMM_TN, 8 * Cout, Kp, B * Lq, mat(_p(dyop), 8 * Ncat, goff=goff_c),
                      mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(dwexp), Kp),

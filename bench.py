@@ -132,17 +132,19 @@ class KernelTimer:
     def wrap_conv_wgrad(self, H):
         orig = H.conv_wgrad
 
-        def timed(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw):
+        def timed(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw, **kw):
             if not self.enabled:
-                return orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw)
+                return orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            ok = orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw)
+            ok = orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B, L, Cout, Cin, k, dw, **kw)
             e.record()
             if ok:
                 planes = 2 if dy_lo is not None else 1
                 # algorithmic bytes: dy column block and padded x once (bf16, per plane), dW read+written (atomics)
-                byts = 2.0 * planes * (B * L * Cout + B * xrows * Cin) + 8.0 * Cout * k * Cin
+                # (Toeplitz form: the input operand is one sequence of ~8 rows-of-8 per sample, not xrows x 64)
+                x_elems = B * (8.0 * L + 64.0 * k) if kw.get("tap_row_step") else float(B) * xrows * Cin
+                byts = 2.0 * planes * (B * L * Cout + x_elems) + 8.0 * Cout * k * Cin
                 self.records.setdefault("conv1d_wgrad", []).append((s, e, 2.0 * B * L * Cout * k * Cin, byts))
             return ok
         H.conv_wgrad = timed

@@ -417,6 +417,14 @@ typedef struct ac_wgrad_desc {
     int64_t ldw;
     int64_t dy_lo_off, x_lo_off;
     int32_t variant;              /* 0: v_mfma_f32_16x16x32 tiles (default); 2: the 32x32x16 form (A/B tests) */
+    /* Toeplitz form (0 = plain): the weight gradient of a Cin = 1 convolution (SpectraNet stage 1) as
+     * dWexp[(p, co), kk] = sum_m dy[m, (p, co)] * x[8 m + kk], m = groups of 8 output positions.  tap_row_step = 8
+     * with x_row_stride = 8 and Cin = 64: "input row" r is the 64-element view x[8 r ..], tap t reads rows
+     * (m + 8 t), i.e. kk = 64 t + ci; dw = dWexp with ldw = its row length (k * 64).  dy_block > 0: column c of a
+     * dy row lives at (c / dy_block) * dy_block_stride + c % dy_block (the 8 positions of a group are 8 rows of
+     * the channels-last gradient; dy_block = Cout of the conv, dy_block % 8 == 0).  Split-bf16 operands only. */
+    int32_t tap_row_step, dy_block;
+    int64_t dy_block_stride;
 } ac_wgrad_desc;
 int ac_conv1d_wgrad_bf16(const ac_wgrad_desc *d, ac_stream_t stream);
 

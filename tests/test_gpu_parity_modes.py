@@ -376,3 +376,43 @@ def test_conv_bank_cin1_toeplitz_on_the_ring_kernel(dev, math_mode, B, L, Cout, 
     for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
         assert rel(a, w_) <= 5e-5, (i, rel(a, w_))
         assert rel(a, b_) <= 2e-5, (i, rel(a, b_))
+
+
+@pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
+def test_stage1_bank_with_layernorm_all_planes(dev, math_mode):
+    """Stage 1 as SpectraNetBlock runs it (Cin = 1 bank -> LayerNorm -> GELU): forward Toeplitz products on the ring
+    kernel, LayerNorm backward writing the (hi, lo) planes of d(conv outputs), Toeplitz weight gradients on the
+    LDS-window weight-gradient kernel — against the round-2 path (gather-GEMM products on fp32 operands) and fp64."""
+    import math
+    import torch.nn.functional as F
+    from applecider_amd import hipops as H
+    B, L, Cout, ks = 2, 4096, 64, (3, 61, 1021)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 1, L, generator=gen, dtype=torch.float64)
+    ws = [(torch.randn(Cout, 1, k, generator=gen, dtype=torch.float64) / math.sqrt(k)).requires_grad_() for k in ks]
+    bs = [torch.randn(Cout, generator=gen, dtype=torch.float64).requires_grad_() for _ in ks]
+    gam = (1 + 0.1 * torch.randn(3 * Cout, generator=gen, dtype=torch.float64)).requires_grad_()
+    bet = (0.1 * torch.randn(3 * Cout, generator=gen, dtype=torch.float64)).requires_grad_()
+    y = torch.cat([F.conv1d(x, w, b, padding=k // 2) for w, b, k in zip(ws, bs, ks)], 1)
+    z = F.gelu(F.layer_norm(y.permute(0, 2, 1), (3 * Cout,), gam, bet, 1e-5))
+    go = torch.randn(*z.shape, generator=gen, dtype=torch.float64)
+    z.backward(go)
+    res = {}
+    for new in (True, False):
+        H._TOEPLITZ_RING = new
+        try:
+            xd = x.float().permute(0, 2, 1).contiguous().to(dev)
+            wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
+            bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
+            gd, btd = gam.detach().float().to(dev).requires_grad_(), bet.detach().float().to(dev).requires_grad_()
+            zd = H.conv_group1d(xd, ks, wd, bd, ln=(gd, btd, 1e-5))
+            zd.backward(go.float().to(dev))
+            torch.cuda.synchronize()
+        finally:
+            H._TOEPLITZ_RING = True
+        res[new] = [zd.detach()] + [w.grad for w in wd] + [b.grad for b in bd] + [gd.grad, btd.grad]
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+    want = [z.detach()] + [w.grad.permute(0, 2, 1).reshape(Cout, -1) for w in ws] + [b.grad for b in bs] + [gam.grad, bet.grad]
+    for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
+        assert rel(a, w_) <= 1e-4, (i, rel(a, w_))
+        assert rel(a, b_) <= 5e-5, (i, rel(a, b_))

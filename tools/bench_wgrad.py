@@ -21,10 +21,10 @@ records = {}
 orig = H.conv_wgrad
 
 
-def timed(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B_, L, Cout, Cin, k, dw):
+def timed(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B_, L, Cout, Cin, k, dw, **kw):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    ok = orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B_, L, Cout, Cin, k, dw)
+    ok = orig(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, B_, L, Cout, Cin, k, dw, **kw)
     e.record()
     if ok:
         records.setdefault((L, Cin, Cout, k, H._X3_VARIANT), []).append((s, e, 2.0 * B_ * L * Cout * k * Cin))

@@ -28,11 +28,11 @@ on = [False]
 og, ow, owg = H.gemm, H.conv_window, H.conv_wgrad
 
 
-def twg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw):
+def twg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw, **kw):
     if not on[0]:
-        return owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw)
+        return owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw, **kw)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(); ok = owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw); e.record()
+    s.record(); ok = owg(dy, dy_lo, dbs, drs, drb, dco, x, x_lo, xbs, xrs, xrb, xrows, Bn, L, Cout, Cin, k, dw, **kw); e.record()
     if ok:
         recs.setdefault(("WGR", Cout, k * Cin, Bn * L, "-", 1), []).append((s, e, 2.0 * Bn * L * Cout * k * Cin))
     return ok
