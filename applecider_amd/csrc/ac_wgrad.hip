@@ -217,6 +217,9 @@ __global__ __launch_bounds__(512, 1) void conv1d_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
                 const int tap = 2 * wn + tp;
+                // Toeplitz form: K is padded to 64-element taps and the last chunk of 8 is mostly past the end
+                // (k = 1021: 17 taps) — a wave skips the taps that do not exist (wave-uniform)
+                if (TOEP && t0 + tap >= d.k) continue;
                 bf16x8 b_h[4], b_l[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
