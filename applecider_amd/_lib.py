@@ -166,8 +166,13 @@ SIGNATURES = {
     "ac_clip_coef": [_P, _F, _P, _P],
     "ac_ceil_copy": [_P, _P, _I64, _P],
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "ac_gemm_batched": [C.POINTER(GemmDesc), _I32, _I64, _I64, _I64, _P],
+    "ac_fft_rows_fwd": [_P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "ac_fft_rows_inv": [_P, _I32, _I32, _I32, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P],
+    "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "ac_fft_taps_inv": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 _RESTYPES = {"ac_strerror": C.c_char_p}
 
 _lib = None

@@ -1,0 +1,131 @@
+// In-LDS FFT core of the frequency-domain convolutions (ac_fft.hip).  Host-compilable on purpose: the CPU test
+// harness (tests/fft_core_harness.cpp) runs exactly these functions, work item by work item, against a direct DFT,
+// so that the index algebra is proven before a kernel ever runs on the GPU.
+//
+// One complex sequence of N = 2^logn points lives in a padded image: element i at phys(i) = i + (i >> 3) (one spare
+// 8-byte slot per 8 elements), sequences seq_pitch(logn) slots apart (= 4 mod 32).  With that padding every access
+// pattern below is (near) bank-conflict free for 8-byte LDS accesses:
+//   * passes with a large stride: the lanes of a wave walk consecutive elements;
+//   * the pass with stride 8: element blk*64 + i0 + 8m -> slot 72 blk + i0 + 9m: 4 blocks x 8 i0 = 32 distinct slots;
+//   * the pass with stride 1 (a lane owns 8 consecutive elements): slot 9u + m, 9 odd: 32 distinct slots.
+// Forward = decimation in frequency (natural order in, bit-reversed order out), inverse = decimation in time
+// (bit-reversed in, natural out): neither direction ever permutes.  A pass performs R <= 3 radix-2 stages on 2^R
+// points held in registers, so a 2048-point transform is 4 LDS round trips instead of 11.  Per pass and work item only
+// R twiddles come from the table (w, w^2, w^4 of the item's base index); the other factors are 8th roots of unity.
+#pragma once
+#ifdef __HIPCC__
+#define AC_FFT_HD __host__ __device__ __forceinline__
+#else
+#define AC_FFT_HD inline
+#endif
+
+typedef float ac_c2 __attribute__((ext_vector_type(2)));   // (re, im)
+
+namespace acfft {
+
+AC_FFT_HD int phys(int i) { return i + (i >> 3); }
+AC_FFT_HD int seq_pitch(int logn) { return (1 << logn) + (1 << (logn - 3)) + 4; }
+
+AC_FFT_HD ac_c2 cmul(ac_c2 a, ac_c2 w) { return ac_c2{a[0] * w[0] - a[1] * w[1], a[0] * w[1] + a[1] * w[0]}; }
+AC_FFT_HD ac_c2 conj(ac_c2 a) { return ac_c2{a[0], -a[1]}; }
+
+// t * exp(-+ 2 pi i K / 8), K in 0..3 (sign -: forward, SIGN_PLUS: inverse)
+template <bool SIGN_PLUS>
+AC_FFT_HD ac_c2 rot8(ac_c2 t, int K) {
+    const float h = 0.70710678118654752440f;
+    switch (K & 3) {
+        case 0: return t;
+        case 1: return SIGN_PLUS ? ac_c2{(t[0] - t[1]) * h, (t[0] + t[1]) * h} : ac_c2{(t[0] + t[1]) * h, (t[1] - t[0]) * h};
+        case 2: return SIGN_PLUS ? ac_c2{-t[1], t[0]} : ac_c2{t[1], -t[0]};
+        default: return SIGN_PLUS ? ac_c2{-(t[0] + t[1]) * h, (t[0] - t[1]) * h} : ac_c2{(t[1] - t[0]) * h, -(t[0] + t[1]) * h};
+    }
+}
+
+// R radix-2 DIF stages starting at stage s0 (block size N >> s0), work item u < N >> R.
+// tw(e, j) = exp(-2 pi i j / (N >> e)), j < N >> (e + 1): the table of the transform of size N >> e.  The kernels keep
+// all levels back to back (level e at element N - (N >> e)), so that the lanes of a wave read consecutive entries.
+template <int R, typename TW>
+AC_FFT_HD void dif_pass(ac_c2 *seq, TW tw, int logn, int s0, int u) {
+    constexpr int P = 1 << R;
+    const int lq = logn - s0 - R;
+    const int blk = u >> lq, i0 = u & ((1 << lq) - 1);
+    const int base = (blk << (logn - s0)) + i0;
+    ac_c2 v[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = seq[phys(base + (m << lq))];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int d = 1 << (R - 1 - r);
+        const ac_c2 wr = tw(s0 + r, i0);
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            if (m & d) continue;
+            const ac_c2 a = v[m], b = v[m + d];
+            v[m] = a + b;
+            v[m + d] = cmul(rot8<false>(a - b, (m & (d - 1)) * (4 / d)), wr);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < P; ++m) seq[phys(base + (m << lq))] = v[m];
+}
+
+// R radix-2 DIT stages of the INVERSE transform starting at half = 1 << lh0, work item u < N >> R.
+// Uses conj(tw).
+template <int R, typename TW>
+AC_FFT_HD void dit_pass(ac_c2 *seq, TW tw, int logn, int lh0, int u) {
+    constexpr int P = 1 << R;
+    const int blk = u >> lh0, i0 = u & ((1 << lh0) - 1);
+    const int base = (blk << (lh0 + R)) + i0;
+    ac_c2 v[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = seq[phys(base + (m << lh0))];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int d = 1 << r;
+        const ac_c2 wr = conj(tw(logn - 1 - lh0 - r, i0));
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            if (m & d) continue;
+            const ac_c2 a = v[m], b = rot8<true>(cmul(v[m + d], wr), (m & (d - 1)) * (4 / d));
+            v[m] = a + b;
+            v[m + d] = a - b;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < P; ++m) seq[phys(base + (m << lh0))] = v[m];
+}
+
+// Pass plan: the first DIF pass takes logn % 3 stages (none when 0), every other pass 3; the inverse mirrors it
+// (its LAST pass takes logn % 3).  Both therefore meet the stride-1 data with an R = 3 pass.
+AC_FFT_HD int first_r(int logn) { return logn % 3; }
+
+// position in the bit-reversed image of the conjugate partner N - f of the frequency f = brev(i)
+AC_FFT_HD int partner(int i) {
+    if (i <= 1) return i;
+    const int k = 31 - __builtin_clz((unsigned)i);   // i in [2^k, 2^(k+1)): the partner is its mirror image there
+    return 3 * (1 << k) - 1 - i;
+}
+AC_FFT_HD int brev(int i, int logn) {
+    unsigned v = (unsigned)i;
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    v = (v >> 16) | (v << 16);
+    return (int)(v >> (32 - logn));
+}
+
+// Two real sequences travel as one complex one, z = x1 + i x2.  From Z[f] and Z[N - f]:
+AC_FFT_HD void untangle(ac_c2 zf, ac_c2 zn, ac_c2 &x1, ac_c2 &x2) {
+    const ac_c2 zc = conj(zn);
+    x1 = (zf + zc) * 0.5f;
+    const ac_c2 d = (zf - zc) * 0.5f;                 // X2 = d / i
+    x2 = ac_c2{d[1], -d[0]};
+}
+// and back: Z[f] = Y1[f] + i Y2[f], Z[N - f] = conj(Y1[f]) + i conj(Y2[f])
+AC_FFT_HD void tangle(ac_c2 y1, ac_c2 y2, ac_c2 &zf, ac_c2 &zn) {
+    zf = ac_c2{y1[0] - y2[1], y1[1] + y2[0]};
+    zn = ac_c2{y1[0] + y2[1], y2[0] - y1[1]};
+}
+
+}  // namespace acfft

@@ -34,7 +34,20 @@ struct GemmParams {
     int tiles_m, tiles_n, nkt, kt_per_split;
     int vec_epi;  // 1: 16-byte epilogue (all C-side pointers/strides 16-byte aligned, N % 4 == 0)
     int epi_var;  // compile-time epilogue variant (AC_EPI_VARIANTS index) or EPI_GENERIC
+    // ac_gemm_batched: gridDim.x = batch * tiles; product z reads / writes its operands bs_* elements further on
+    int64_t bs_a, bs_b, bs_c;
 };
+
+// Batched instantiations: workgroup id -> (product z, tile), operand pointers of product z.  The XCD-aware order
+// is taken over the flattened (z, tile) range, so the tiles of one product (which share its A and B) run on one XCD.
+__device__ __forceinline__ void batch_select(const GemmParams &p, int &wg, ac_gemm_desc &d) {
+    const int per = p.tiles_m * p.tiles_n, z = wg / per;
+    wg -= z * per;
+    d = p.d;
+    d.a.ptr = (const float *)d.a.ptr + (int64_t)z * p.bs_a;
+    d.b.ptr = (const float *)d.b.ptr + (int64_t)z * p.bs_b;
+    d.c.ptr = (float *)d.c.ptr + (int64_t)z * p.bs_c;
+}
 
 // round-to-nearest-even fp32 -> bf16 (the rounding ac_cast_bf16 applies)
 __device__ __forceinline__ unsigned short epi_bf16(float x) {
@@ -435,10 +448,9 @@ __device__ __forceinline__ f32x4 read_frag(const float *tile, int local /* row o
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool BATCH = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const ac_gemm_desc &d = p.d;
     const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -448,7 +460,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     // XCD-aware tile order: workgroups that share an XCD (bid % 8) walk contiguous tiles
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    ac_gemm_desc dz;
+    if constexpr (BATCH) batch_select(p, wg, dz);
+    const ac_gemm_desc &d = BATCH ? dz : p.d;
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
     const int kt_begin = blockIdx.y * p.kt_per_split;
@@ -892,14 +907,13 @@ __device__ __forceinline__ bf16x8 frag_x3(const unsigned short *img, int colbase
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool BATCH = false>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm16 = reinterpret_cast<unsigned short *>(smem);
     constexpr int A_IMG = A_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int B_IMG = B_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;
-    const ac_gemm_desc &d = p.d;
     const uint64_t dseed = ac_step_seed(p.d.drop_seed, p.d.drop_step);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -908,7 +922,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    ac_gemm_desc dz;
+    if constexpr (BATCH) batch_select(p, wg, dz);
+    const ac_gemm_desc &d = BATCH ? dz : p.d;
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
     const int kt_begin = blockIdx.y * p.kt_per_split;
@@ -1005,16 +1022,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
         store_tile(d, dseed, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool BATCH = false>
 int launch_x3(const GemmParams &p, dim3 grid, hipStream_t stream) {
     constexpr int A_IMG = A_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int B_IMG = B_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int LDS = 2 * (2 * A_IMG + 2 * B_IMG) * 2;   // two stages, bytes
     static_assert(LDS >= 4 * 2048 * 4, "the 16-byte epilogue parks 8 KB per wave in this buffer");
-    static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_x3_kernel<A_KC, B_KC>,
+    static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_x3_kernel<A_KC, B_KC, BATCH>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC>), grid, dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, BATCH>), grid, dim3(256), LDS, stream, p);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -1359,7 +1376,7 @@ int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
 
 }  // namespace
 
-extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
+static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int64_t bs_a, int64_t bs_b, int64_t bs_c) {
     if (!dp) return AC_EINVAL;
     ac_gemm_desc d = *dp;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1378,6 +1395,7 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
 
     if (d.math == AC_MATH_BF16_IN) {
         // operands are bf16 in memory: strides / offsets in bf16 elements, multiples of 8 (16 B)
+        if (batch > 1) return AC_EINVAL;
         if (d.mode == AC_GEMM_NN) return AC_EINVAL;  // transpose B at cast time and use NT
         auto al8 = [](const ac_rowmap &r) { return r.s1 % 8 == 0 && r.s2 % 8 == 0 && r.s3 % 8 == 0; };
         const int ai = d.mode == AC_GEMM_TN ? d.M : d.K, bi = d.mode == AC_GEMM_TN ? d.N : d.K;
@@ -1415,12 +1433,13 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     bool aligned = ac_aligned16(d.a.ptr) && ac_aligned16(d.b.ptr) && rowmap_aligned(d.a.rows) &&
                    rowmap_aligned(d.b.rows) && (a_inner % 4 == 0) && (b_inner % 4 == 0);
     const double macs = (double)d.M * d.N * d.K;
-    bool use_mfma = aligned && !d.force_simple && macs >= 262144.0;
+    bool use_mfma = aligned && !d.force_simple && (macs >= 262144.0 || batch > 1);
 
     GemmParams p;
     p.d = d;
+    p.bs_a = bs_a; p.bs_b = bs_b; p.bs_c = bs_c;
     if (!use_mfma) {
-        if (d.accumulate == 3) return AC_EINVAL;   // split-K slabs exist on the matrix-core kernels only
+        if (d.accumulate == 3 || batch > 1) return AC_EINVAL;   // split-K slabs / batches exist on the matrix-core kernels only
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
         // and honours the caller's accumulate mode.
         p.tiles_m = p.tiles_n = p.nkt = p.kt_per_split = p.vec_epi = 0;
@@ -1453,6 +1472,26 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
     const size_t lds_f32 = 4 * TILE_FLOATS * sizeof(float);  // 64 KB
     const size_t lds_bf16 = 4 * TILE_FLOATS * sizeof(short); // 32 KB
+    if (batch > 1) {
+        // the per-frequency products of the frequency-domain convolutions (ac_fft.hip): plain fp32 matrices, no
+        // epilogue beyond store / +=, exact fp32 or split-bf16 arithmetic
+        if (d.split_k != 1 || d.math == AC_MATH_BF16 || (int64_t)batch * grid.x > 0x7FFFFFFF) return AC_EINVAL;
+        if ((bs_a % 4) || (bs_b % 4) || (bs_c % 4)) return AC_EALIGN;
+        grid.x *= batch;
+        if (d.math == AC_MATH_BF16X3) {
+            if (d.mode == AC_GEMM_NT) return launch_x3<true, true, true>(p, grid, stream);
+            if (d.mode == AC_GEMM_NN) return launch_x3<true, false, true>(p, grid, stream);
+            return launch_x3<false, false, true>(p, grid, stream);
+        }
+        if (d.mode == AC_GEMM_NT)
+            hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, dim3(256), lds_f32, stream, p);
+        else if (d.mode == AC_GEMM_NN)
+            hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), lds_f32, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), lds_f32, stream, p);
+        AC_CHECK_LAUNCH();
+        return AC_OK;
+    }
     if (d.math == AC_MATH_BF16X3) {
         if (d.mode == AC_GEMM_NT) return launch_x3<true, true>(p, grid, stream);
         if (d.mode == AC_GEMM_NN) return launch_x3<true, false>(p, grid, stream);
@@ -1475,6 +1514,14 @@ extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream_) {
     }
     AC_CHECK_LAUNCH();
     return AC_OK;
+}
+
+extern "C" int ac_gemm(const ac_gemm_desc *dp, ac_stream_t stream) { return gemm_run(dp, stream, 1, 0, 0, 0); }
+
+extern "C" int ac_gemm_batched(const ac_gemm_desc *dp, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c,
+                               ac_stream_t stream) {
+    if (batch < 1) return AC_EINVAL;
+    return gemm_run(dp, stream, batch, bs_a, bs_b, bs_c);
 }
 
 extern "C" int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream) {

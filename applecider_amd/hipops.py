@@ -1607,6 +1607,107 @@ def global_max(x):
     return _GlobalMax.apply(x)
 
 
+# --------------------------------------------------------------------------- frequency-domain conv products
+_FFTCONV = True       # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
+_FFT_MIN_K = 48       # taps from which the transform form wins (measured: tools/bench_fftconv.py)
+_FFT_MATH = _lib.MATH_F32   # arithmetic of the per-frequency products: exact fp32 matrix cores (HBM-bound either way)
+_fft_tables: dict = {}
+
+
+def _fft_tw(logn: int, device) -> torch.Tensor:
+    """Twiddle table of ac_fft_*: level e (transform size N >> e) = exp(-2 pi i j / (N >> e)), j < N >> (e + 1),
+    levels back to back.  Built once per size in fp64 on the host."""
+    key = (logn, str(device))
+    t = _fft_tables.get(key)
+    if t is None:
+        N = 1 << logn
+        parts = []
+        for e in range(logn):
+            n = N >> e
+            ang = -2.0 * torch.pi * torch.arange(n // 2, dtype=torch.float64) / n
+            parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=1))
+        parts.append(torch.zeros(1, 2, dtype=torch.float64))
+        t = _fft_tables[key] = torch.cat(parts).to(torch.float32).to(device)
+    return t
+
+
+def fft_logn(L: int, k: int):
+    """log2 of the transform length of a 'same' Conv1d with k taps on L positions: N >= L + k // 2 (the circular
+    wrap of the k // 2 positions past either end of the linear convolution falls outside the cropped output)."""
+    need = L + k // 2
+    logn = max(6, (need - 1).bit_length())
+    return logn if logn <= 11 and k <= (1 << logn) else None
+
+
+def fftconv_covered(L: int, Cin: int, Cout: int, k: int) -> bool:
+    return bool(_FFTCONV and _MATH in (_lib.MATH_F32, _lib.MATH_BF16X3) and _MODE != "f16" and k >= _FFT_MIN_K
+                and Cin % 16 == 0 and Cout % 16 == 0 and fft_logn(L, k) is not None)
+
+
+def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, logn) -> torch.Tensor:
+    """Spectrum [N/2 + 1, B, 2 Cn] of the channels-last rows src[b, l, col_off + c] (fp32, or (hi, lo) bf16 planes)."""
+    spec = torch.empty((1 << (logn - 1)) + 1, B, 2 * Cn, device=src.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_fft_rows_fwd(_p(src, elem_off), _p(src_lo, elem_off), batch_stride, row_stride, col_off, B, L,
+                                       Cn, shift, logn, _p(_fft_tw(logn, src.device)), _p(spec), _stream()),
+               "ac_fft_rows_fwd")
+    return spec
+
+
+def fft_rows_inv(spec, B, Cn, logn, dst, batch_stride, row_stride, col_off, L, shift, bias, accumulate):
+    _lib.check(_lib_().ac_fft_rows_inv(_p(spec), B, Cn, logn, _p(_fft_tw(logn, spec.device)), _p(dst), batch_stride,
+                                       row_stride, col_off, L, shift, _p(bias), int(accumulate), _stream()),
+               "ac_fft_rows_inv")
+
+
+def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c, math=None):
+    d = GemmDesc()
+    d.mode, d.math = mode, (_FFT_MATH if math is None else math)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.split_k, d.alpha = 1, 1.0
+    d.a, d.b, d.c = a, b, c
+    _lib.check(_lib_().ac_gemm_batched(C.byref(d), int(batch), int(bs_a), int(bs_b), int(bs_c), _stream()),
+               "ac_gemm_batched")
+
+
+def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias):
+    """out[b, l, col_off + co] = bias[co] + sum_{t, ci} x[b, l + t - k//2, ci] w[co, t, ci] through the frequency
+    domain (spectranet.py:18-20,25).  x [B, L, Cin] fp32 contiguous, w [Cout, k * Cin] tap-major.  Returns what the
+    gradient products reuse: (spectrum of x, block form of the taps' spectrum, logn)."""
+    logn = fft_logn(L, k)
+    F = (1 << (logn - 1)) + 1
+    dev = x.device
+    xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0, logn)
+    hb = torch.empty(F, 2 * Cout, 2 * Cin, device=dev, dtype=torch.float32)
+    _lib.check(_lib_().ac_fft_taps_fwd(_p(w), Cout, Cin, k, logn, _p(_fft_tw(logn, dev)), _p(hb), _stream()),
+               "ac_fft_taps_fwd")
+    yf = torch.empty(F, B, 2 * Cout, device=dev, dtype=torch.float32)
+    gemm_batched(AC_GEMM_NT, B, 2 * Cout, 2 * Cin, mat(_p(xf), 2 * Cin), mat(_p(hb), 2 * Cin), mat(_p(yf), 2 * Cout),
+                 F, B * 2 * Cin, 4 * Cout * Cin, B * 2 * Cout)
+    fft_rows_inv(yf, B, Cout, logn, out, L * ld_out, ld_out, col_off, L, k - 1 - k // 2, bias, False)
+    return xf, hb, logn
+
+
+def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cin, Cout, k,
+                     dx, dx_accumulate, dw):
+    """Gradient products of fftconv_forward: dx [B, L, Cin] (nullable; stored or accumulated) and dw [Cout, k * Cin]
+    (accumulated into).  dy: fp32 rows, or (dy, dy_lo) bf16 planes."""
+    xf, hb, logn = saved
+    F = (1 << (logn - 1)) + 1
+    dev = xf.device
+    gf = fft_rows_fwd(dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cout, k - 1 - k // 2, logn)
+    if dx is not None:
+        dxf = torch.empty(F, B, 2 * Cin, device=dev, dtype=torch.float32)
+        gemm_batched(AC_GEMM_NN, B, 2 * Cin, 2 * Cout, mat(_p(gf), 2 * Cout), mat(_p(hb), 2 * Cin), mat(_p(dxf), 2 * Cin),
+                     F, B * 2 * Cout, 4 * Cout * Cin, B * 2 * Cin)
+        fft_rows_inv(dxf, B, Cin, logn, dx, L * Cin, Cin, 0, L, 0, None, dx_accumulate)
+    if dw is not None:
+        mp = torch.empty(F, 2 * Cout, 2 * Cin, device=dev, dtype=torch.float32)
+        gemm_batched(AC_GEMM_TN, 2 * Cout, 2 * Cin, B, mat(_p(gf), 2 * Cout), mat(_p(xf), 2 * Cin), mat(_p(mp), 2 * Cin),
+                     F, B * 2 * Cout, B * 2 * Cin, 4 * Cout * Cin)
+        _lib.check(_lib_().ac_fft_taps_inv(_p(mp), Cout, Cin, k, logn, _p(_fft_tw(logn, dev)), _p(dw), _stream()),
+                   "ac_fft_taps_inv")
+
+
 def _pad_rows(x, B, L, Cn, pad_lo, Lp):
     y = torch.empty(B, Lp, Cn, device=x.device, dtype=torch.float32)
     _lib.check(_lib_().ac_pad_rows(_p(x), _p(y), B, L, Cn, pad_lo, Lp, _stream()), "ac_pad_rows")

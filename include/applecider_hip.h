@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AC_ABI_VERSION 3
+#define AC_ABI_VERSION 4
 
 #define AC_OK 0
 #define AC_EINVAL (-22)     /* bad argument / unsupported shape            */
@@ -581,6 +581,42 @@ int ac_clip_coef(const float *sumsq, float max_norm, float *coef, ac_stream_t st
 int ac_ceil_copy(const void *src, void *dst, int64_t bytes, ac_stream_t stream);
 int ac_ceil_mfma(const void *ops, float *out, int32_t shape, int32_t workgroups, int32_t waves_per_wg,
                  int32_t iters, ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Frequency-domain form of the long-tap Conv1d products of a SpectraNetBlock (spectranet.py:18-20,25 and torch's
+ * conv1d backward; stage 2 of default_config.toml:104-114 is Conv1d(64 -> 128, k = 251) on 1024 positions).  With
+ * N = 2^logn >= L + k/2 the three products of one convolution are
+ *     y  = irfft( rfft(x) H )          dx = irfft( rfft(dy) conj(H)^T )          dw = irfft( conj(rfft(x))^T rfft(dy) )
+ * per frequency f <= N/2 — about k / log2(N) times fewer FLOP than the direct form, in fp32 throughout.
+ * Spectra are [N/2 + 1][B][2C] fp32 (a complex number = two adjacent columns: re, im).
+ *
+ * ac_gemm_batched: `batch` independent products of one shape in one launch; product z takes its operands
+ *   bs_a / bs_b / bs_c ELEMENTS after those of product z - 1 (multiples of 4).  math = AC_MATH_F32 or
+ *   AC_MATH_BF16X3, split_k = 1, 16-byte aligned operands (the matrix-core kernels; AC_EINVAL otherwise).
+ * Twiddle table `tw`, provided by the caller (the library never allocates): N - 1 complex (2 floats each) entries,
+ *   level e (0 <= e < logn) holds exp(-2 pi i j / (N >> e)), j < N >> (e + 1), at element offset N - (N >> e).
+ * ac_fft_rows_fwd: rows src[b, l, col_off + c] (element at b * batch_stride + l * row_stride + col_off + c; fp32, or —
+ *   src_lo non-null — a (hi, lo) bf16 plane pair of the same strides whose sum is the value), l < L, c < C, placed at
+ *   sequence index l + shift of a zero-filled length-N sequence -> spec [N/2 + 1][B][2C].  C % 16 == 0, 6 <= logn <= 11.
+ * ac_fft_rows_inv: the inverse, scaled by 1/N: dst[b, l, col_off + c] (+)= seq[l + shift] + bias[c] (bias nullable).
+ * ac_fft_taps_fwd: taps w[co][t][ci] -> hblock [N/2 + 1][2 Cout][2 Cin], the real block form [[Hr, -Hi], [Hi, Hr]]
+ *   of the spectrum of h[m] = w[co][k - 1 - m][ci]: y = x * h at sequence offset k - 1 - k/2 is the 'same' correlation
+ *   of nn.Conv1d.  Forward product: NT with A = spectrum of x, B = hblock; input gradient: NN with A = spectrum of dy
+ *   (rows placed at shift k - 1 - k/2), B = hblock.  Cin % 16 == 0.
+ * ac_fft_taps_inv: m [N/2 + 1][2 Cout][2 Cin] = (spectrum of dy)^T (spectrum of x) per frequency (TN product)
+ *   -> dw[co][t][ci] += the weight gradient (dw is accumulated into: zero it or pass the gradient sink).
+ * ---------------------------------------------------------------------- */
+int ac_gemm_batched(const ac_gemm_desc *d, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c, ac_stream_t stream);
+int ac_fft_rows_fwd(const void *src, const void *src_lo, int64_t batch_stride, int64_t row_stride, int32_t col_off,
+                    int32_t B, int32_t L, int32_t C, int32_t shift, int32_t logn, const float *tw, float *spec,
+                    ac_stream_t stream);
+int ac_fft_rows_inv(const float *spec, int32_t B, int32_t C, int32_t logn, const float *tw, float *dst,
+                    int64_t batch_stride, int64_t row_stride, int32_t col_off, int32_t L, int32_t shift,
+                    const float *bias, int32_t accumulate, ac_stream_t stream);
+int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
+                    float *hblock, ac_stream_t stream);
+int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw, float *dw,
+                    ac_stream_t stream);
 
 #ifdef __cplusplus
 }

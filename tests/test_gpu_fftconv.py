@@ -1,0 +1,113 @@
+"""Frequency-domain form of the long-tap Conv1d products (csrc/ac_fft.hip + ac_gemm_batched) against torch's conv1d
+(spectranet.py:18-20: 'same' Conv1d, padding k//2) and its backward in fp64: transforms alone (vs torch.fft), then
+forward, input gradient and weight gradient through the C ABI."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("logn", [6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("planes", [False, True])
+def test_fft_rows_roundtrip_and_spectrum(dev, logn, planes):
+    """rows -> spectrum equals torch.fft.rfft of the shifted, zero-padded rows; spectrum -> rows returns them."""
+    from applecider_amd import hipops as H
+    N = 1 << logn
+    B, Cn, Ctot, col = 3, 32, 80, 16
+    L, shift = N - 11, 5
+    g = torch.Generator().manual_seed(logn)
+    x = torch.randn(B, L, Ctot, generator=g)
+    xd = x.to(dev)
+    if planes:
+        hi, lo = H.split16(xd)
+        spec = H.fft_rows_fwd(hi, lo, 0, L * Ctot, Ctot, col, B, L, Cn, shift, logn)
+        x = (hi.float() + lo.float()).cpu()
+    else:
+        spec = H.fft_rows_fwd(xd, None, 0, L * Ctot, Ctot, col, B, L, Cn, shift, logn)
+    seq = torch.zeros(B, N, Cn, dtype=torch.float64)
+    seq[:, shift:shift + L] = x[:, :, col:col + Cn].double()
+    want = torch.fft.rfft(seq, dim=1)                                   # [B, F, Cn]
+    got = spec.cpu().double().reshape(N // 2 + 1, B, Cn, 2)
+    got = torch.complex(got[..., 0], got[..., 1]).permute(1, 0, 2)
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
+    # inverse: back into a wider tensor at another column, with bias, then accumulated once more
+    out = torch.full((B, L, Ctot), 7.0, device=dev)
+    bias = torch.randn(Cn, generator=g).to(dev)
+    H.fft_rows_inv(spec, B, Cn, logn, out, L * Ctot, Ctot, col + 16, L, shift, bias, False)
+    ref = x[:, :, col:col + Cn].double() + bias.cpu().double()
+    assert _rel(out[:, :, col + 16:col + 16 + Cn], ref) <= 2e-6
+    assert float((out[:, :, :col + 16] - 7.0).abs().max()) == 0.0       # neighbours untouched
+    H.fft_rows_inv(spec, B, Cn, logn, out, L * Ctot, Ctot, col + 16, L, shift, None, True)
+    assert _rel(out[:, :, col + 16:col + 16 + Cn], ref + x[:, :, col:col + Cn].double()) <= 2e-6
+
+
+def _ref_conv(x, w, b, dy, k):
+    """fp64 reference: y, dx, dw (tap-major [Cout, k*Cin]) of the 'same' Conv1d on channels-last x."""
+    xt = x.double().permute(0, 2, 1).requires_grad_(True)
+    Cout, Cin = w.shape[0], x.shape[2]
+    wt = w.double().reshape(Cout, k, Cin).permute(0, 2, 1).contiguous().requires_grad_(True)
+    y = F.conv1d(xt, wt, b.double(), padding=k // 2)
+    gx, gw = torch.autograd.grad(y, (xt, wt), dy.double().permute(0, 2, 1))
+    return y.permute(0, 2, 1), gx.permute(0, 2, 1), gw.permute(0, 2, 1).reshape(Cout, k * Cin)
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,k", [(4, 1024, 64, 128, 251),     # SpectraNet stage 2 (N = 2048)
+                                            (4, 256, 128, 256, 61),      # stage 3 (N = 512)
+                                            (8, 64, 256, 512, 31),       # stage 4 (N = 128)
+                                            (3, 128, 16, 48, 99),        # odd batch, N = 256, 16-channel groups
+                                            (2, 40, 32, 16, 49)])        # L not a power of two, N = 64
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
+    from applecider_amd import _lib, hipops as H
+    g = torch.Generator().manual_seed(k + L)
+    x = torch.randn(B, L, Cin, generator=g)
+    w = torch.randn(Cout, k * Cin, generator=g) / (k * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Ncat, col = Cout + 32, 16
+    dyc = torch.randn(B, L, Ncat, generator=g)
+    dy = dyc[:, :, col:col + Cout]
+    y_ref, dx_ref, dw_ref = _ref_conv(x, w, b, dy, k)
+    old = H._FFT_MATH
+    H._FFT_MATH = _lib.MATH_F32 if math == "f32" else _lib.MATH_BF16X3
+    try:
+        xd, wd = x.to(dev), w.to(dev)
+        out = torch.zeros(B, L, Ncat, device=dev)
+        saved = H.fftconv_forward(xd, wd, B, L, Cin, Cout, k, out, Ncat, col, b.to(dev))
+        tol = 5e-6 if math == "f32" else 5e-5
+        assert _rel(out[:, :, col:col + Cout], y_ref) <= tol
+        assert float(out[:, :, :col].abs().max()) == 0.0 and float(out[:, :, col + Cout:].abs().max()) == 0.0
+        # gradients from fp32 rows of the concatenated gradient ...
+        dyd = dyc.to(dev)
+        dx = torch.empty(B, L, Cin, device=dev)
+        dw = torch.zeros(Cout, k * Cin, device=dev)
+        H.fftconv_backward(saved, dyd, None, 0, L * Ncat, Ncat, col, B, L, Cin, Cout, k, dx, False, dw)
+        assert _rel(dx, dx_ref) <= tol
+        assert _rel(dw, dw_ref) <= tol
+        # ... and from zero-padded (hi, lo) planes as LayerNorm's backward writes them; dx / dw accumulate
+        P = 5
+        hi, lo = H._pad_rows_split(dyd, B, L, Ncat, P, L + 2 * P)
+        H.fftconv_backward(saved, hi, lo, P * Ncat, (L + 2 * P) * Ncat, Ncat, col, B, L, Cin, Cout, k, dx, True, dw)
+        assert _rel(dx, 2 * dx_ref) <= 2 * tol + 2e-5
+        assert _rel(dw, 2 * dw_ref) <= 2 * tol + 2e-5
+    finally:
+        H._FFT_MATH = old
+
+
+def test_fft_entry_points_refuse_bad_shapes(dev):
+    from applecider_amd import _lib, hipops as H
+    lib = _lib.load()
+    z = torch.zeros(4096, device=dev)
+    tw = H._fft_tw(6, dev)
+    s = H._stream()
+    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 4, 8, 0, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL     # C % 16
+    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 60, 16, 8, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL   # L + shift > N
+    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 4, 16, 0, 12, H._p(tw), H._p(z), s) == _lib.AC_EINVAL   # logn > 11
+    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL                      # k > N
+    assert H.fft_logn(1024, 251) == 11 and H.fft_logn(256, 61) == 9 and H.fft_logn(64, 31) == 7
+    assert H.fft_logn(4096, 1021) is None
