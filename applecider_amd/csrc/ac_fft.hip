@@ -35,35 +35,62 @@ struct TwTable {
     __device__ __forceinline__ ac_c2 operator()(int e, int j) const { return ac_gload<ac_c2>(tw + (n - (n >> e)) + j); }
 };
 
-template <int R, bool INVERSE>
+// One pass over the FFT_SEQ sequences of the workgroup.  A thread keeps PASS_U work items in flight: the LDS reads and
+// twiddle loads of all of them are issued before the first butterfly (at 148 KB of LDS a CU holds ONE workgroup = two
+// waves per SIMD, so nothing else hides those latencies).
+// Kernels come in two register budgets: U = 4 (N >= 1024: LDS admits one or two workgroups per CU anyway) and
+// U = 1 (N <= 512: ~52 VGPRs, four workgroups per CU hide the latencies between them).
+template <int R, bool INVERSE, int PASS_U>
 __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int arg) {
-    const int per = 1 << (logn - R), pitch = seq_pitch(logn);
+    const int per = 1 << (logn - R), pitch = seq_pitch(logn), total = FFT_SEQ * per;
     __syncthreads();
-    for (int w = threadIdx.x; w < FFT_SEQ * per; w += FFT_THREADS) {
-        ac_c2 *seq = buf + (w >> (logn - R)) * pitch;
-        const int u = w & (per - 1);
-        if (INVERSE)
-            dit_pass<R>(seq, tw, logn, arg, u);
-        else
-            dif_pass<R>(seq, tw, logn, arg, u);
+    for (int w0 = threadIdx.x; w0 < total; w0 += FFT_THREADS * PASS_U) {
+        ac_c2 v[PASS_U][1 << R], tws[PASS_U][R];
+        PassItem it[PASS_U];
+        ac_c2 *seq[PASS_U];
+#pragma unroll
+        for (int j = 0; j < PASS_U; ++j) {
+            int w = w0 + j * FFT_THREADS;
+            w = w < total ? w : w0;                       // (a clamped duplicate: computed, never stored)
+            seq[j] = buf + (w >> (logn - R)) * pitch;
+            const int u = w & (per - 1);
+            it[j] = INVERSE ? dit_item<R>(arg, u) : dif_item<R>(logn, arg, u);
+            if (INVERSE)
+                dit_twiddles<R>(tw, logn, arg, it[j].i0, tws[j]);
+            else
+                dif_twiddles<R>(tw, arg, it[j].i0, tws[j]);
+            pass_load<R>(seq[j], it[j], v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < PASS_U; ++j) {
+            if (INVERSE)
+                dit_butterflies<R>(v[j], tws[j]);
+            else
+                dif_butterflies<R>(v[j], tws[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < PASS_U; ++j)
+            if (w0 + j * FFT_THREADS < total) pass_store<R>(seq[j], it[j], v[j]);
     }
 }
 
 // natural order in -> bit-reversed order out
+template <int U>
 __device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
-    if (r0 == 1) fft_pass_all<1, false>(buf, tw, logn, 0);
-    if (r0 == 2) fft_pass_all<2, false>(buf, tw, logn, 0);
-    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false>(buf, tw, logn, s);
+    if (r0 == 1) fft_pass_all<1, false, U>(buf, tw, logn, 0);
+    if (r0 == 2) fft_pass_all<2, false, U>(buf, tw, logn, 0);
+    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, U>(buf, tw, logn, s);
     __syncthreads();
 }
 // bit-reversed order in -> natural order out (unnormalised inverse)
+template <int U>
 __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
     int lh = 0;
-    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true>(buf, tw, logn, lh);
-    if (r0 == 1) fft_pass_all<1, true>(buf, tw, logn, lh);
-    if (r0 == 2) fft_pass_all<2, true>(buf, tw, logn, lh);
+    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, U>(buf, tw, logn, lh);
+    if (r0 == 1) fft_pass_all<1, true, U>(buf, tw, logn, lh);
+    if (r0 == 2) fft_pass_all<2, true, U>(buf, tw, logn, lh);
     __syncthreads();
 }
 
@@ -96,8 +123,9 @@ struct RowsParams {
     int logn, accumulate;
 };
 
-template <bool PLANES>
-__global__ __launch_bounds__(FFT_THREADS, 1) void fft_rows_fwd_kernel(RowsParams p) {
+template <bool PLANES, int U>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kernel(RowsParams p) {
+    constexpr int LB = U == 1 ? 2 : 8, SB = U == 1 ? 2 : 4;     // global loads / LDS reads in flight per thread
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
     int b, g;
@@ -106,33 +134,54 @@ __global__ __launch_bounds__(FFT_THREADS, 1) void fft_rows_fwd_kernel(RowsParams
     const TwTable tw{p.tw, N};
     ac_c2 *seq = fbuf + q * pitch;
     const int64_t off = (int64_t)b * p.batch_stride + p.col_off + c0 + 2 * q;
-    for (int n = threadIdx.x >> 3; n < N; n += FFT_THREADS / 8) {
-        const int l = n - p.shift;
-        const bool in = l >= 0 && l < p.L;
-        const int64_t a = off + (int64_t)(in ? l : 0) * p.row_stride;
-        ac_c2 z;
-        if (PLANES) {
-            const unsigned h = ac_gload<unsigned>((const unsigned short *)p.src + a);
-            const unsigned lo = ac_gload<unsigned>((const unsigned short *)p.src_lo + a);
-            z = ac_c2{ac_h2f((unsigned short)(h & 0xFFFFu)) + ac_h2f((unsigned short)(lo & 0xFFFFu)),
-                      ac_h2f((unsigned short)(h >> 16)) + ac_h2f((unsigned short)(lo >> 16))};
-        } else {
-            z = ac_gload<ac_c2>((const float *)p.src + a);
+    constexpr int RS = FFT_THREADS / 8;     // rows per sweep of the workgroup
+    // zeros where no row lands, then the rows with eight loads in flight per thread
+    for (int n = threadIdx.x >> 3; n < N; n += RS)
+        if (n < p.shift || n >= p.shift + p.L) seq[phys(n)] = ac_c2{0.f, 0.f};
+    for (int l0 = threadIdx.x >> 3; l0 < p.L; l0 += RS * LB) {
+        ac_c2 z[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int l = l0 + u * RS;
+            const int64_t a = off + (int64_t)(l < p.L ? l : l0) * p.row_stride;
+            if (PLANES) {
+                const unsigned h = ac_gload<unsigned>((const unsigned short *)p.src + a);
+                const unsigned lo = ac_gload<unsigned>((const unsigned short *)p.src_lo + a);
+                z[u] = ac_c2{ac_h2f((unsigned short)(h & 0xFFFFu)) + ac_h2f((unsigned short)(lo & 0xFFFFu)),
+                             ac_h2f((unsigned short)(h >> 16)) + ac_h2f((unsigned short)(lo >> 16))};
+            } else {
+                z[u] = ac_gload<ac_c2>((const float *)p.src + a);
+            }
         }
-        seq[phys(n)] = in ? z : ac_c2{0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (l0 + u * RS < p.L) seq[phys(l0 + u * RS + p.shift)] = z[u];
     }
-    fft_forward(fbuf, tw, p.logn);
+    fft_forward<U>(fbuf, tw, p.logn);
     float *dst = p.dst + (int64_t)b * (2 * p.C) + 2 * (c0 + 2 * q);
     const int64_t fstride = (int64_t)p.B * (2 * p.C);
-    for (int idx = threadIdx.x >> 3; idx <= halfn; idx += FFT_THREADS / 8) {
-        const int i = half_pos(idx, halfn), f = brev(i, p.logn);
-        ac_c2 x1, x2;
-        untangle(seq[phys(i)], seq[phys(partner(i))], x1, x2);
-        *(f32x4 *)(dst + (int64_t)f * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
+    for (int idx0 = threadIdx.x >> 3; idx0 <= halfn; idx0 += RS * SB) {
+        ac_c2 zf[SB], zn[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = idx0 + u * RS, i = half_pos(idx <= halfn ? idx : idx0, halfn);
+            zf[u] = seq[phys(i)];
+            zn[u] = seq[phys(partner(i))];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = idx0 + u * RS;
+            if (idx > halfn) continue;
+            ac_c2 x1, x2;
+            untangle(zf[u], zn[u], x1, x2);
+            *(f32x4 *)(dst + (int64_t)brev(half_pos(idx, halfn), p.logn) * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
+        }
     }
 }
 
-__global__ __launch_bounds__(FFT_THREADS, 1) void fft_rows_inv_kernel(RowsParams p) {
+template <int U>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kernel(RowsParams p) {
+    constexpr int LB = U == 1 ? 2 : 8;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
     int b, g;
@@ -142,24 +191,41 @@ __global__ __launch_bounds__(FFT_THREADS, 1) void fft_rows_inv_kernel(RowsParams
     ac_c2 *seq = fbuf + q * pitch;
     const float *src = (const float *)p.src + (int64_t)b * (2 * p.C) + 2 * (c0 + 2 * q);
     const int64_t fstride = (int64_t)p.B * (2 * p.C);
-    for (int idx = threadIdx.x >> 3; idx <= halfn; idx += FFT_THREADS / 8) {
-        const int i = half_pos(idx, halfn), f = brev(i, p.logn);
-        const f32x4 v = ac_gload<f32x4>(src + (int64_t)f * fstride);
-        ac_c2 zf, zn;
-        tangle(ac_c2{v[0], v[1]}, ac_c2{v[2], v[3]}, zf, zn);
-        seq[phys(i)] = zf;
-        if (i > 1) seq[phys(partner(i))] = zn;
+    constexpr int RS = FFT_THREADS / 8;
+    for (int idx0 = threadIdx.x >> 3; idx0 <= halfn; idx0 += RS * LB) {
+        f32x4 v[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int idx = idx0 + u * RS;
+            v[u] = ac_gload<f32x4>(src + (int64_t)brev(half_pos(idx <= halfn ? idx : idx0, halfn), p.logn) * fstride);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int idx = idx0 + u * RS;
+            if (idx > halfn) continue;
+            const int i = half_pos(idx, halfn);
+            ac_c2 zf, zn;
+            tangle(ac_c2{v[u][0], v[u][1]}, ac_c2{v[u][2], v[u][3]}, zf, zn);
+            seq[phys(i)] = zf;
+            if (i > 1) seq[phys(partner(i))] = zn;
+        }
     }
-    fft_inverse(fbuf, tw, p.logn);
+    fft_inverse<U>(fbuf, tw, p.logn);
     const float inv = 1.0f / (float)N;
     float *dst = p.dst + (int64_t)b * p.batch_stride + p.col_off + c0 + 2 * q;
     ac_c2 bias2 = {0.f, 0.f};
     if (p.bias) bias2 = ac_gload<ac_c2>(p.bias + c0 + 2 * q);
-    for (int l = threadIdx.x >> 3; l < p.L; l += FFT_THREADS / 8) {
-        ac_c2 o = seq[phys(l + p.shift)] * inv + bias2;
-        ac_c2 *d = (ac_c2 *)(dst + (int64_t)l * p.row_stride);
-        if (p.accumulate) o += *d;
-        *d = o;
+    for (int l0 = threadIdx.x >> 3; l0 < p.L; l0 += RS * LB) {
+        ac_c2 o[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int l = l0 + u * RS < p.L ? l0 + u * RS : l0;
+            o[u] = seq[phys(l + p.shift)] * inv + bias2;
+            if (p.accumulate) o[u] += ac_gload<ac_c2>(dst + (int64_t)l * p.row_stride);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (l0 + u * RS < p.L) *(ac_c2 *)(dst + (int64_t)(l0 + u * RS) * p.row_stride) = o[u];
     }
 }
 
@@ -171,7 +237,8 @@ struct TapsParams {
 };
 
 // workgroup = (co, 16 input channels): h[m] = w[co][k - 1 - m][ci], pairs of ci transformed together
-__global__ __launch_bounds__(FFT_THREADS, 1) void fft_taps_fwd_kernel(TapsParams p) {
+template <int U>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kernel(TapsParams p) {
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
     const int G = p.Cin >> 4, co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 16;
@@ -184,7 +251,7 @@ __global__ __launch_bounds__(FFT_THREADS, 1) void fft_taps_fwd_kernel(TapsParams
         const ac_c2 z = ac_gload<ac_c2>(w + (int64_t)(in ? p.k - 1 - m : 0) * p.Cin);
         seq[phys(m)] = in ? z : ac_c2{0.f, 0.f};
     }
-    fft_forward(fbuf, tw, p.logn);
+    fft_forward<U>(fbuf, tw, p.logn);
     // H'[f][(co, re)][(ci, re)] = Hr, [(co, re)][(ci, im)] = -Hi, [(co, im)][(ci, re)] = Hi, [(co, im)][(ci, im)] = Hr
     const int ld = 2 * p.Cin;
     float *o = p.dst + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);
@@ -200,7 +267,8 @@ __global__ __launch_bounds__(FFT_THREADS, 1) void fft_taps_fwd_kernel(TapsParams
 }
 
 // workgroup = (co, 16 input channels): conj(X_f) G_f for the pairs of ci from the rows (co, re), (co, im) of M'
-__global__ __launch_bounds__(FFT_THREADS, 1) void fft_taps_inv_kernel(TapsParams p) {
+template <int U>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kernel(TapsParams p) {
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
     const int G = p.Cin >> 4, co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 16;
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(FFT_THREADS, 1) void fft_taps_inv_kernel(TapsParams
         seq[phys(i)] = zf;
         if (i > 1) seq[phys(partner(i))] = zn;
     }
-    fft_inverse(fbuf, tw, p.logn);
+    fft_inverse<U>(fbuf, tw, p.logn);
     const float inv = 1.0f / (float)N;
     float *dw = p.dst + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
     for (int t = threadIdx.x >> 3; t < p.k; t += FFT_THREADS / 8) {
@@ -258,8 +326,12 @@ extern "C" int ac_fft_rows_fwd(const void *src, const void *src_lo, int64_t batc
     p.src = src; p.src_lo = src_lo; p.dst = spec; p.tw = (const ac_c2 *)tw; p.bias = nullptr;
     p.row_stride = row_stride; p.batch_stride = batch_stride; p.col_off = col_off;
     p.B = B; p.C = C; p.L = L; p.shift = shift; p.logn = logn; p.accumulate = 0;
-    if (src_lo) return fft_launch(fft_rows_fwd_kernel<true>, B * (C / 16), p, logn, (hipStream_t)stream);
-    return fft_launch(fft_rows_fwd_kernel<false>, B * (C / 16), p, logn, (hipStream_t)stream);
+    const int blocks = B * (C / 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_lo) return logn >= 10 ? fft_launch(fft_rows_fwd_kernel<true, 4>, blocks, p, logn, st)
+                                  : fft_launch(fft_rows_fwd_kernel<true, 1>, blocks, p, logn, st);
+    return logn >= 10 ? fft_launch(fft_rows_fwd_kernel<false, 4>, blocks, p, logn, st)
+                      : fft_launch(fft_rows_fwd_kernel<false, 1>, blocks, p, logn, st);
 }
 
 extern "C" int ac_fft_rows_inv(const float *spec, int32_t B, int32_t C, int32_t logn, const float *tw, float *dst,
@@ -274,7 +346,8 @@ extern "C" int ac_fft_rows_inv(const float *spec, int32_t B, int32_t C, int32_t 
     p.src = spec; p.src_lo = nullptr; p.dst = dst; p.tw = (const ac_c2 *)tw; p.bias = bias;
     p.row_stride = row_stride; p.batch_stride = batch_stride; p.col_off = col_off;
     p.B = B; p.C = C; p.L = L; p.shift = shift; p.logn = logn; p.accumulate = accumulate;
-    return fft_launch(fft_rows_inv_kernel, B * (C / 16), p, logn, (hipStream_t)stream);
+    return logn >= 10 ? fft_launch(fft_rows_inv_kernel<4>, B * (C / 16), p, logn, (hipStream_t)stream)
+                      : fft_launch(fft_rows_inv_kernel<1>, B * (C / 16), p, logn, (hipStream_t)stream);
 }
 
 extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -284,7 +357,8 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     if (((uintptr_t)w & 7u) || !ac_aligned16(hblock) || ((uintptr_t)tw & 7u)) return AC_EALIGN;
     TapsParams p;
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
-    return fft_launch(fft_taps_fwd_kernel, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
+    return logn >= 10 ? fft_launch(fft_taps_fwd_kernel<4>, Cout * (Cin / 16), p, logn, (hipStream_t)stream)
+                      : fft_launch(fft_taps_fwd_kernel<1>, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
 }
 
 extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -294,5 +368,6 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     if (!ac_aligned16(m) || ((uintptr_t)tw & 7u) || ((uintptr_t)dw & 7u)) return AC_EALIGN;
     TapsParams p;
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
-    return fft_launch(fft_taps_inv_kernel, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
+    return logn >= 10 ? fft_launch(fft_taps_inv_kernel<4>, Cout * (Cin / 16), p, logn, (hipStream_t)stream)
+                      : fft_launch(fft_taps_inv_kernel<1>, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
 }

@@ -41,58 +41,92 @@ AC_FFT_HD ac_c2 rot8(ac_c2 t, int K) {
     }
 }
 
-// R radix-2 DIF stages starting at stage s0 (block size N >> s0), work item u < N >> R.
+// A pass = R radix-2 stages on P = 2^R points of one work item u < N >> R, in four pieces (address, load, twiddles +
+// butterflies, store) so that a kernel thread can keep several work items in flight: all their LDS reads and twiddle
+// loads are issued before the first butterfly.
 // tw(e, j) = exp(-2 pi i j / (N >> e)), j < N >> (e + 1): the table of the transform of size N >> e.  The kernels keep
 // all levels back to back (level e at element N - (N >> e)), so that the lanes of a wave read consecutive entries.
-template <int R, typename TW>
-AC_FFT_HD void dif_pass(ac_c2 *seq, TW tw, int logn, int s0, int u) {
-    constexpr int P = 1 << R;
+struct PassItem {
+    int base, lstride, i0;    // element index of point 0, log2 of the distance between points, twiddle index
+};
+// forward (decimation in frequency), stages s0 .. s0 + R - 1 (block size N >> s0)
+template <int R>
+AC_FFT_HD PassItem dif_item(int logn, int s0, int u) {
     const int lq = logn - s0 - R;
     const int blk = u >> lq, i0 = u & ((1 << lq) - 1);
-    const int base = (blk << (logn - s0)) + i0;
-    ac_c2 v[P];
+    return PassItem{(blk << (logn - s0)) + i0, lq, i0};
+}
+// inverse (decimation in time), halves 1 << lh0 .. 1 << (lh0 + R - 1)
+template <int R>
+AC_FFT_HD PassItem dit_item(int lh0, int u) {
+    const int blk = u >> lh0, i0 = u & ((1 << lh0) - 1);
+    return PassItem{(blk << (lh0 + R)) + i0, lh0, i0};
+}
+template <int R>
+AC_FFT_HD void pass_load(const ac_c2 *seq, const PassItem &it, ac_c2 (&v)[1 << R]) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) v[m] = seq[phys(base + (m << lq))];
+    for (int m = 0; m < (1 << R); ++m) v[m] = seq[phys(it.base + (m << it.lstride))];
+}
+template <int R>
+AC_FFT_HD void pass_store(ac_c2 *seq, const PassItem &it, const ac_c2 (&v)[1 << R]) {
+#pragma unroll
+    for (int m = 0; m < (1 << R); ++m) seq[phys(it.base + (m << it.lstride))] = v[m];
+}
+template <int R, typename TW>
+AC_FFT_HD void dif_twiddles(TW tw, int s0, int i0, ac_c2 (&w)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = tw(s0 + r, i0);
+}
+template <int R, typename TW>
+AC_FFT_HD void dit_twiddles(TW tw, int logn, int lh0, int i0, ac_c2 (&w)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = conj(tw(logn - 1 - lh0 - r, i0));
+}
+template <int R>
+AC_FFT_HD void dif_butterflies(ac_c2 (&v)[1 << R], const ac_c2 (&w)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int d = 1 << (R - 1 - r);
-        const ac_c2 wr = tw(s0 + r, i0);
 #pragma unroll
-        for (int m = 0; m < P; ++m) {
+        for (int m = 0; m < (1 << R); ++m) {
             if (m & d) continue;
             const ac_c2 a = v[m], b = v[m + d];
             v[m] = a + b;
-            v[m + d] = cmul(rot8<false>(a - b, (m & (d - 1)) * (4 / d)), wr);
+            v[m + d] = cmul(rot8<false>(a - b, (m & (d - 1)) * (4 / d)), w[r]);
         }
     }
-#pragma unroll
-    for (int m = 0; m < P; ++m) seq[phys(base + (m << lq))] = v[m];
 }
-
-// R radix-2 DIT stages of the INVERSE transform starting at half = 1 << lh0, work item u < N >> R.
-// Uses conj(tw).
-template <int R, typename TW>
-AC_FFT_HD void dit_pass(ac_c2 *seq, TW tw, int logn, int lh0, int u) {
-    constexpr int P = 1 << R;
-    const int blk = u >> lh0, i0 = u & ((1 << lh0) - 1);
-    const int base = (blk << (lh0 + R)) + i0;
-    ac_c2 v[P];
-#pragma unroll
-    for (int m = 0; m < P; ++m) v[m] = seq[phys(base + (m << lh0))];
+template <int R>
+AC_FFT_HD void dit_butterflies(ac_c2 (&v)[1 << R], const ac_c2 (&w)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int d = 1 << r;
-        const ac_c2 wr = conj(tw(logn - 1 - lh0 - r, i0));
 #pragma unroll
-        for (int m = 0; m < P; ++m) {
+        for (int m = 0; m < (1 << R); ++m) {
             if (m & d) continue;
-            const ac_c2 a = v[m], b = rot8<true>(cmul(v[m + d], wr), (m & (d - 1)) * (4 / d));
+            const ac_c2 a = v[m], b = rot8<true>(cmul(v[m + d], w[r]), (m & (d - 1)) * (4 / d));
             v[m] = a + b;
             v[m + d] = a - b;
         }
     }
-#pragma unroll
-    for (int m = 0; m < P; ++m) seq[phys(base + (m << lh0))] = v[m];
+}
+template <int R, typename TW>
+AC_FFT_HD void dif_pass(ac_c2 *seq, TW tw, int logn, int s0, int u) {
+    const PassItem it = dif_item<R>(logn, s0, u);
+    ac_c2 v[1 << R], w[R];
+    pass_load<R>(seq, it, v);
+    dif_twiddles<R>(tw, s0, it.i0, w);
+    dif_butterflies<R>(v, w);
+    pass_store<R>(seq, it, v);
+}
+template <int R, typename TW>
+AC_FFT_HD void dit_pass(ac_c2 *seq, TW tw, int logn, int lh0, int u) {
+    const PassItem it = dit_item<R>(lh0, u);
+    ac_c2 v[1 << R], w[R];
+    pass_load<R>(seq, it, v);
+    dit_twiddles<R>(tw, logn, lh0, it.i0, w);
+    dit_butterflies<R>(v, w);
+    pass_store<R>(seq, it, v);
 }
 
 // Pass plan: the first DIF pass takes logn % 3 stages (none when 0), every other pass 3; the inverse mirrors it

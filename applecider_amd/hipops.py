@@ -1609,8 +1609,8 @@ def global_max(x):
 
 # --------------------------------------------------------------------------- frequency-domain conv products
 _FFTCONV = True       # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
-_FFT_MIN_K = 48       # taps from which the transform form wins (measured: tools/bench_fftconv.py)
-_FFT_MATH = _lib.MATH_F32   # arithmetic of the per-frequency products: exact fp32 matrix cores (HBM-bound either way)
+_FFT_MATH = None      # arithmetic of the per-frequency products: None = the math mode's (fp32 or split-bf16 matrix cores)
+_FFT_FORCE = False    # tests: the transform form wherever the kernels cover the shape, whatever the cost rule says
 _fft_tables: dict = {}
 
 
@@ -1639,9 +1639,25 @@ def fft_logn(L: int, k: int):
     return logn if logn <= 11 and k <= (1 << logn) else None
 
 
-def fftconv_covered(L: int, Cin: int, Cout: int, k: int) -> bool:
-    return bool(_FFTCONV and _MATH in (_lib.MATH_F32, _lib.MATH_BF16X3) and _MODE != "f16" and k >= _FFT_MIN_K
-                and Cin % 16 == 0 and Cout % 16 == 0 and fft_logn(L, k) is not None)
+def fftconv_covered(B: int, L: int, Cin: int, Cout: int, k: int) -> bool:
+    """Whether the three products of a 'same' Conv1d run in the frequency domain.  Shape limits of the kernels, and
+    a cost rule from tools/bench_fftconv.py (profiles/r03_fftconv_kernels_*.txt): the transform form moves about
+    7 x the bytes of one (input + output) spectrum pair plus the taps' spectrum once per product at ~2.6 TB/s whatever
+    k is; the direct window kernels sustain ~500 TFLOP/s of the 6 B L Cin Cout k FLOP.  SpectraNet's default stages
+    (default_config.toml:104-114): k = 251 (12.0 -> 2.2 ms), k = 61 (3.1 -> 1.0 ms) and stage 4's k = 31 (1.7 -> 0.8 ms)
+    go through the transforms, every shorter kernel stays direct."""
+    if not (_FFTCONV and _MATH in (_lib.MATH_F32, _lib.MATH_BF16X3) and _MODE != "f16" and Cin % 16 == 0
+            and Cout % 16 == 0 and k % 2 == 1):
+        return False
+    logn = fft_logn(L, k)
+    if logn is None:
+        return False
+    if _FFT_FORCE:
+        return True
+    N, F = 1 << logn, (1 << (logn - 1)) + 1
+    fft_ms = (7.0 * B * N * (Cin + Cout) * 4 + 3.0 * F * 4 * Cin * Cout * 4) / 2.6e9
+    direct_ms = 6.0 * B * L * Cin * Cout * k / 500e9
+    return direct_ms >= 1.25 * fft_ms
 
 
 def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, logn) -> torch.Tensor:
@@ -1661,7 +1677,9 @@ def fft_rows_inv(spec, B, Cn, logn, dst, batch_stride, row_stride, col_off, L, s
 
 def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c, math=None):
     d = GemmDesc()
-    d.mode, d.math = mode, (_FFT_MATH if math is None else math)
+    if math is None:
+        math = _FFT_MATH if _FFT_MATH is not None else (_lib.MATH_BF16X3 if _MATH == _lib.MATH_BF16X3 else _lib.MATH_F32)
+    d.mode, d.math = mode, math
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.split_k, d.alpha = 1, 1.0
     d.a, d.b, d.c = a, b, c
@@ -1753,6 +1771,7 @@ class _ConvGroup1d(Function):
         Pmax = max(ksizes) // 2
         dev = x.device
         ctx.ksizes, ctx.dims = tuple(ksizes), (B, L, Cin, Cout, Pmax)
+        ctx.fft = {}       # conv index -> (spectrum of x, block spectrum of the taps, logn) of the frequency-domain form
         ctx.has_b = [b is not None for b in bs]
         b16 = ctx.b16 = bf16_operands()
         mth = _lib.MATH_BF16_IN if b16 else None
@@ -1832,6 +1851,10 @@ class _ConvGroup1d(Function):
             xpad = None if planes_only else (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
+                if not b16 and fftconv_covered(B, L, Cin, Cout, k):
+                    # long taps: the three products of this convolution run in the frequency domain (ac_fft.hip)
+                    ctx.fft[j] = fftconv_forward(x, ws[j], B, L, Cin, Cout, k, ycat, Ncat, j * Cout, bs[j])
+                    continue
                 if xplanes is not None and conv_window_x3(
                         xplanes, Lp * Cin, Cin, 0, off, B, L, Cin, k, split16_w(ws[j]), k * Cin, Cin, False, Cout,
                         _p(ycat, j * Cout), Ncat, bs[j], False):
@@ -2033,6 +2056,20 @@ class _ConvGroup1d(Function):
             for j, k in enumerate(ksizes):
                 p = k // 2
                 off = Pmax - p
+                if j in ctx.fft:
+                    wsink = _sink(ctx.params[0][j])
+                    dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev, dtype=torch.float32)
+                    if dycat is not None:      # fp32 rows of d(ycat)
+                        src = (dycat, None, 0, L * Ncat)
+                    else:                      # the zero-padded (hi, lo) planes LayerNorm's backward wrote
+                        src = (dyplanes[0], dyplanes[1], Pmax * Ncat, Lpd * Ncat)
+                    fftconv_backward(ctx.fft[j], src[0], src[1], src[2], src[3], Ncat, j * Cout, B, L, Cin, Cout, k,
+                                     dx if ctx.needs_input_grad[0] else None, j > 0, dw)
+                    if wsink is not None:
+                        dw = None
+                        _grad_written(ctx.params[0][j])
+                    grads += [dw, bias_grad(j)]
+                    continue
                 if ctx.needs_input_grad[0] and dyplanes is not None and conv_window_x3(
                         dyplanes, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, split16_wT(ctx.params[0][j]),
                         Cout, Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):

@@ -147,6 +147,28 @@ def test_spectranet_golden(dev, gmode):
     assert_close(norms, g["full.gradnorm_all"], GRAD_TOL, "full grad norms")
 
 
+def test_spectranet_golden_frequency_domain(dev, gmode):
+    """The full-size network against the reference's golden g4 with EVERY covered convolution of stages 2-5 in the
+    frequency domain (ac_fft.hip; at B = 2 the cost rule alone would keep them direct): same bounds."""
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    from applecider_amd import hipops as H
+    g = gold("g4_spectranet.npz")
+    H._FFT_FORCE = True
+    try:
+        m = build(SpectraNet, cfg_default(), dev).eval()
+        b = make_batch(2, seed=4)
+        logits = m((T(b["spectra"]).to(dev), None, None))
+        assert_close(logits, g["full.logits"], LOGIT_TOL, "full logits")
+        loss = H.cross_entropy_index(logits, T(b["label"]).to(dev))
+        assert_close(loss, g["full.loss"], LOGIT_TOL, "full loss")
+        loss.backward()
+    finally:
+        H._FFT_FORCE = False
+    norms = np.array([p.grad.norm().item() for p in m.parameters()], dtype=np.float32)
+    assert_close(norms, g["full.gradnorm_all"], GRAD_TOL, "full grad norms")
+
+
 def test_spectranet_train_step_golden(dev, gmode):
     """C3 (spectranet.py:172-184): train_step under the injected SGD(0.01, 0.9) + CrossEntropyLoss with
     the int16 labels the reference's to_tensor emits, two steps (momentum buffer), against the

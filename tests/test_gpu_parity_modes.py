@@ -257,7 +257,7 @@ def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
 
 
 @pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
-@pytest.mark.parametrize("fused", [True, False, "round2"])
+@pytest.mark.parametrize("fused", [True, False, "round2", "fft"])
 @pytest.mark.parametrize("B,L,Cin,Cout,ks", [(2, 256, 64, 128, (3, 31, 251)), (2, 128, 128, 64, (3, 15, 61)),
                                              (1, 256, 256, 128, (7, 13, 31)), (2, 64, 128, 256, (3, 15, 61)),
                                              (8, 64, 128, 256, (3, 11, 31)), (32, 16, 512, 128, (3, 7, 13)),
@@ -282,15 +282,18 @@ def test_conv_bank_bf16x3_vs_fp64(dev, math_mode, fused, B, L, Cin, Cout, ks):
     wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
     bd = [b.detach().float().to(dev).requires_grad_() for b in bs]
     # True: the default = the round-3 ring kernel (weights by LDS-DMA into a ring of half-stages, fragments prefetched
-    # across the barrier) where it applies; "round2": the round-2 kernel everywhere; False: three bf16 passes
+    # across the barrier) where it applies; "round2": the round-2 kernel everywhere; False: three bf16 passes;
+    # "fft": every convolution of the bank through the frequency domain (ac_fft.hip), whatever the cost rule says
     H._CONVWIN_X3_FUSED = bool(fused)
     H._X3_VARIANT = 4 if fused == "round2" else 0
+    H._FFT_FORCE = fused == "fft"
     try:
         yd = H.conv_group1d(xd, ks, wd, bd)
         yd.backward(go.float().permute(0, 2, 1).contiguous().to(dev))
     finally:
         H._CONVWIN_X3_FUSED = True
         H._X3_VARIANT = 0
+        H._FFT_FORCE = False
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
     tol = 5e-5
     assert rel(yd.permute(0, 2, 1), y.detach()) <= tol
@@ -321,8 +324,9 @@ def test_conv_bank_layernorm_backward_writes_the_operand_planes(dev, math_mode, 
     go = torch.randn(*z.shape, generator=gen, dtype=torch.float64)
     z.backward(go)
     res = {}
-    for planes in (True, False):
-        H._LN_PLANES = planes
+    for planes in (True, False, "fft"):     # "fft": the planes feed the frequency-domain products (ac_fft_rows_fwd)
+        H._LN_PLANES = bool(planes)
+        H._FFT_FORCE = planes == "fft"
         try:
             xd = x.detach().float().permute(0, 2, 1).contiguous().to(dev).requires_grad_()
             wd = [w.detach().float().permute(0, 2, 1).reshape(Cout, -1).contiguous().to(dev).requires_grad_() for w in ws]
@@ -333,12 +337,15 @@ def test_conv_bank_layernorm_backward_writes_the_operand_planes(dev, math_mode, 
             torch.cuda.synchronize()
         finally:
             H._LN_PLANES = True
+            H._FFT_FORCE = False
         res[planes] = [xd.grad] + [w.grad for w in wd] + [b.grad for b in bd] + [gd.grad, btd.grad]
     rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
     want = [x.grad.permute(0, 2, 1)] + [w.grad.permute(0, 2, 1).reshape(Cout, -1) for w in ws] + [b.grad for b in bs] + [gam.grad, bet.grad]
     for i, (a, b_, w_) in enumerate(zip(res[True], res[False], want)):
         assert rel(a, b_) <= 2e-6, (i, rel(a, b_))
         assert rel(a, w_) <= 1e-4, (i, rel(a, w_))
+    for i, (a, w_) in enumerate(zip(res["fft"], want)):
+        assert rel(a, w_) <= 1e-4, ("fft", i, rel(a, w_))
 
 
 @pytest.mark.parametrize("math_mode", ["bf16x3"], indirect=True)
