@@ -72,6 +72,14 @@ class WgradDesc(C.Structure):
                 ("tap_row_step", C.c_int32), ("dy_block", C.c_int32), ("dy_block_stride", C.c_int64)]
 
 
+class FftRowsDesc(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("rows_lo", C.c_void_p), ("spec", C.c_void_p), ("tw", C.c_void_p),
+                ("bias", C.c_void_p), ("batch_stride", C.c_int64), ("row_stride", C.c_int64),
+                ("col_off", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("logn", C.c_int32),
+                ("blocks", C.c_int32), ("block_step", C.c_int32), ("shift", C.c_int32),
+                ("n_lo", C.c_int32), ("n_hi", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class TowerDesc(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in
                  ("x", "w1", "b1", "lnm_g", "lnm_b", "lng_g", "lng_b", "wm", "bm", "wg", "bg", "ws", "bs", "y", "save",
@@ -167,8 +175,8 @@ SIGNATURES = {
     "ac_ceil_copy": [_P, _P, _I64, _P],
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_gemm_batched": [C.POINTER(GemmDesc), _I32, _I64, _I64, _I64, _P],
-    "ac_fft_rows_fwd": [_P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
-    "ac_fft_rows_inv": [_P, _I32, _I32, _I32, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _I32, _P],
+    "ac_fft_rows_fwd": [C.POINTER(FftRowsDesc), _P],
+    "ac_fft_rows_inv": [C.POINTER(FftRowsDesc), _P],
     "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "ac_fft_taps_inv": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
 }

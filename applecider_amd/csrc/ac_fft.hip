@@ -3,20 +3,23 @@
 // Conv1d(Cin -> Cout, k, padding k//2) on L positions (src/applecider/models/spectranet.py:18-20; stage 2 of the
 // default configuration: 64 -> 128 channels, k = 251, L = 1024, default_config.toml:104-114) costs 2 B L Cout Cin k FLOP
 // directly — 2.16 TFLOP per product at B = 512, three products per training step — but only
-//     Y_f[b, co] = sum_ci X_f[b, ci] H_f[ci, co]        for every frequency f of a length-N transform, N >= L + k//2
+//     Y_f[b, co] = sum_ci X_f[b, ci] H_f[ci, co]        for every frequency f of a length-N transform
 // = N/2 + 1 small complex products (34 GFLOP in all) once the operands are in the frequency domain.  The complex
 // products run as real batched products on the matrix cores (ac_gemm_batched; a complex number = two adjacent real
 // columns); this file holds the transforms around them, all on the in-LDS core of ac_fft_core.h:
-//   ac_fft_rows_fwd   channels-last real rows [B, L, C] (fp32, or a (hi, lo) bf16 plane pair) -> spectrum [F][B][2C]
-//   ac_fft_rows_inv   spectrum [F][B][2C] -> channels-last real rows (cropped at an offset, + bias, or accumulated)
+//   ac_fft_rows_fwd   channels-last real rows [B, L, C] (fp32, or a (hi, lo) bf16 plane pair) -> spectrum [F][B*blocks][2C]
+//   ac_fft_rows_inv   spectrum -> channels-last real rows (cropped at an offset, + bias, or accumulated)
 //   ac_fft_taps_fwd   taps w[co][t][ci] (flipped: a correlation) -> H' [F][2 Cout][2 Cin], the real block form
 //                     [[Hr, -Hi], [Hi, Hr]]: the [N][K] operand of the forward product and, read as [K][N], the
 //                     operand of the input-gradient product (its transpose is the block form of conj H)
 //   ac_fft_taps_inv   M' [F][2 Cout][2 Cin] = G'^T X' per frequency -> conj(X_f) G_f = (M'_rr + M'_ii) + i (M'_ir - M'_ri)
 //                     -> inverse transform, cropped to the k taps, flipped, added into dw[co][t][ci]
+// A sample is either ONE sequence (N >= L + k//2: the circular wrap falls into the zero padding) or `blocks`
+// overlapping windows of N points that advance by V = N - k + 1 rows (overlap-save): shorter transforms, the same
+// spectrum bytes, four workgroups per CU instead of one.
 // Real sequences are transformed two at a time (z = x1 + i x2; adjacent channels are an 8-byte load) and untangled
-// through Z[f] and conj Z[N - f]; a workgroup of 512 threads holds 8 complex sequences (16 channels) of N <= 2048 points
-// (148 KB of LDS at N = 2048).  fp32 throughout: 2-5e-7 of the direct convolution (profiles/r03_fftconv_probe.txt).
+// through Z[f] and conj Z[N - f]; a workgroup of 512 threads holds 8 complex sequences (16 channels; 148 KB of LDS at
+// N = 2048) or, for N <= 128, 32 of them (64 channels).  fp32 throughout: 2-5e-7 of the direct convolution.
 #include "ac_common.h"
 #include "ac_fft_core.h"
 #include <type_traits>
@@ -26,7 +29,6 @@ namespace {
 using namespace acfft;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FFT_SEQ = 8;        // complex sequences per workgroup
 constexpr int FFT_THREADS = 512;
 
 struct TwTable {
@@ -35,14 +37,14 @@ struct TwTable {
     __device__ __forceinline__ ac_c2 operator()(int e, int j) const { return ac_gload<ac_c2>(tw + (n - (n >> e)) + j); }
 };
 
-// One pass over the FFT_SEQ sequences of the workgroup.  A thread keeps PASS_U work items in flight: the LDS reads and
+// One pass over the SEQ sequences of the workgroup.  A thread keeps PASS_U work items in flight: the LDS reads and
 // twiddle loads of all of them are issued before the first butterfly (at 148 KB of LDS a CU holds ONE workgroup = two
 // waves per SIMD, so nothing else hides those latencies).
 // Kernels come in two register budgets: U = 4 (N >= 1024: LDS admits one or two workgroups per CU anyway) and
 // U = 1 (N <= 512: ~52 VGPRs, four workgroups per CU hide the latencies between them).
-template <int R, bool INVERSE, int PASS_U>
+template <int R, bool INVERSE, int SEQ, int PASS_U>
 __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int arg) {
-    const int per = 1 << (logn - R), pitch = seq_pitch(logn), total = FFT_SEQ * per;
+    const int per = 1 << (logn - R), pitch = seq_pitch(logn, SEQ), total = SEQ * per;
     __syncthreads();
     for (int w0 = threadIdx.x; w0 < total; w0 += FFT_THREADS * PASS_U) {
         ac_c2 v[PASS_U][1 << R], tws[PASS_U][R];
@@ -75,22 +77,22 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
 }
 
 // natural order in -> bit-reversed order out
-template <int U>
+template <int SEQ, int U>
 __device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
-    if (r0 == 1) fft_pass_all<1, false, U>(buf, tw, logn, 0);
-    if (r0 == 2) fft_pass_all<2, false, U>(buf, tw, logn, 0);
-    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, U>(buf, tw, logn, s);
+    if (r0 == 1) fft_pass_all<1, false, SEQ, U>(buf, tw, logn, 0);
+    if (r0 == 2) fft_pass_all<2, false, SEQ, U>(buf, tw, logn, 0);
+    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U>(buf, tw, logn, s);
     __syncthreads();
 }
 // bit-reversed order in -> natural order out (unnormalised inverse)
-template <int U>
+template <int SEQ, int U>
 __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
     int lh = 0;
-    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, U>(buf, tw, logn, lh);
-    if (r0 == 1) fft_pass_all<1, true, U>(buf, tw, logn, lh);
-    if (r0 == 2) fft_pass_all<2, true, U>(buf, tw, logn, lh);
+    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U>(buf, tw, logn, lh);
+    if (r0 == 1) fft_pass_all<1, true, SEQ, U>(buf, tw, logn, lh);
+    if (r0 == 2) fft_pass_all<2, true, SEQ, U>(buf, tw, logn, lh);
     __syncthreads();
 }
 
@@ -98,69 +100,28 @@ __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int l
 // below N / 2, position 1 is N / 2
 __device__ __forceinline__ int half_pos(int idx, int halfn) { return idx == halfn ? 1 : 2 * idx; }
 
-// workgroups that share a batch row (its channel groups read / write the same 128-byte lines) sit on one XCD
-__device__ __forceinline__ void map_block(int bid, int B, int G, int &b, int &g) {
-    if ((B & 7) == 0) {
+// workgroups that share a spectrum row (its channel groups read / write the same 128-byte lines) sit on one XCD
+__device__ __forceinline__ void map_block(int bid, int rows, int G, int &row, int &g) {
+    if ((rows & 7) == 0) {
         const int xcd = bid & 7, slot = bid >> 3;
         g = slot % G;
-        b = (slot / G) * 8 + xcd;
+        row = (slot / G) * 8 + xcd;
     } else {
         g = bid % G;
-        b = bid / G;
+        row = bid / G;
     }
 }
 
 struct RowsParams {
-    const void *src;       // fwd: real rows (fp32, or the hi plane); inv: spectrum
-    const void *src_lo;    // fwd: lo plane (bf16) or null
-    float *dst;            // fwd: spectrum; inv: real rows
-    const ac_c2 *tw;
-    const float *bias;     // inv only, nullable, indexed by channel
-    int64_t row_stride, batch_stride;   // of the real tensor (elements)
-    int col_off;           // first channel column of the real tensor
-    int B, C, L;           // C channels transformed (C % 16 == 0), L valid rows
-    int shift;             // real row l <-> sequence index l + shift
-    int logn, accumulate;
+    ac_fft_rows_desc d;
 };
 
-template <bool PLANES, int U>
-__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kernel(RowsParams p) {
-    constexpr int LB = U == 1 ? 2 : 8, SB = U == 1 ? 2 : 4;     // global loads / LDS reads in flight per thread
-    extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
-    int b, g;
-    map_block(blockIdx.x, p.B, p.C >> 4, b, g);
-    const int q = threadIdx.x & 7, c0 = g * 16;
-    const TwTable tw{p.tw, N};
-    ac_c2 *seq = fbuf + q * pitch;
-    const int64_t off = (int64_t)b * p.batch_stride + p.col_off + c0 + 2 * q;
-    constexpr int RS = FFT_THREADS / 8;     // rows per sweep of the workgroup
-    // zeros where no row lands, then the rows with eight loads in flight per thread
-    for (int n = threadIdx.x >> 3; n < N; n += RS)
-        if (n < p.shift || n >= p.shift + p.L) seq[phys(n)] = ac_c2{0.f, 0.f};
-    for (int l0 = threadIdx.x >> 3; l0 < p.L; l0 += RS * LB) {
-        ac_c2 z[LB];
-#pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int l = l0 + u * RS;
-            const int64_t a = off + (int64_t)(l < p.L ? l : l0) * p.row_stride;
-            if (PLANES) {
-                const unsigned h = ac_gload<unsigned>((const unsigned short *)p.src + a);
-                const unsigned lo = ac_gload<unsigned>((const unsigned short *)p.src_lo + a);
-                z[u] = ac_c2{ac_h2f((unsigned short)(h & 0xFFFFu)) + ac_h2f((unsigned short)(lo & 0xFFFFu)),
-                             ac_h2f((unsigned short)(h >> 16)) + ac_h2f((unsigned short)(lo >> 16))};
-            } else {
-                z[u] = ac_gload<ac_c2>((const float *)p.src + a);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LB; ++u)
-            if (l0 + u * RS < p.L) seq[phys(l0 + u * RS + p.shift)] = z[u];
-    }
-    fft_forward<U>(fbuf, tw, p.logn);
-    float *dst = p.dst + (int64_t)b * (2 * p.C) + 2 * (c0 + 2 * q);
-    const int64_t fstride = (int64_t)p.B * (2 * p.C);
-    for (int idx0 = threadIdx.x >> 3; idx0 <= halfn; idx0 += RS * SB) {
+// LDS image <-> spectrum [F][rows][2C]: every lane moves one (frequency, channel pair) = 16 bytes
+template <int SEQ, int SB>
+__device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int64_t fstride, int logn) {
+    const int halfn = 1 << (logn - 1);
+    constexpr int RS = FFT_THREADS / SEQ;
+    for (int idx0 = threadIdx.x / SEQ; idx0 <= halfn; idx0 += RS * SB) {
         ac_c2 zf[SB], zn[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -174,30 +135,68 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
             if (idx > halfn) continue;
             ac_c2 x1, x2;
             untangle(zf[u], zn[u], x1, x2);
-            *(f32x4 *)(dst + (int64_t)brev(half_pos(idx, halfn), p.logn) * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
+            *(f32x4 *)(dst + (int64_t)brev(half_pos(idx, halfn), logn) * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
         }
     }
 }
 
-template <int U>
-__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kernel(RowsParams p) {
-    constexpr int LB = U == 1 ? 2 : 8;
+template <int SEQ, int U, bool PLANES>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kernel(RowsParams p) {
+    constexpr int LB = U == 1 ? 2 : 8, SB = U == 1 ? 2 : 4;     // global loads / LDS reads in flight per thread
+    constexpr int RS = FFT_THREADS / SEQ;                        // rows per sweep of the workgroup
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
-    int b, g;
-    map_block(blockIdx.x, p.B, p.C >> 4, b, g);
-    const int q = threadIdx.x & 7, c0 = g * 16;
-    const TwTable tw{p.tw, N};
+    const ac_fft_rows_desc &d = p.d;
+    const int N = 1 << d.logn, pitch = seq_pitch(d.logn, SEQ);
+    int row, g;
+    map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
+    const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
+    const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
+    const TwTable tw{(const ac_c2 *)d.tw, N};
     ac_c2 *seq = fbuf + q * pitch;
-    const float *src = (const float *)p.src + (int64_t)b * (2 * p.C) + 2 * (c0 + 2 * q);
-    const int64_t fstride = (int64_t)p.B * (2 * p.C);
-    constexpr int RS = FFT_THREADS / 8;
-    for (int idx0 = threadIdx.x >> 3; idx0 <= halfn; idx0 += RS * LB) {
+    // sequence indices [n0, n1) take the rows l = rv + n - shift; everything else is zero
+    int n0 = d.shift - rv, n1 = d.L + d.shift - rv;
+    n0 = n0 > d.n_lo ? n0 : d.n_lo;
+    n1 = n1 < d.n_hi ? n1 : d.n_hi;
+    n1 = n1 < N ? n1 : N;
+    n1 = n1 > n0 ? n1 : n0;
+    for (int n = threadIdx.x / SEQ; n < N; n += RS)
+        if (n < n0 || n >= n1) seq[phys(n)] = ac_c2{0.f, 0.f};
+    const int cnt = n1 - n0;
+    const int64_t off = (int64_t)b * d.batch_stride + (int64_t)(rv + n0 - d.shift) * d.row_stride + d.col_off + c0 + 2 * q;
+    for (int j0 = threadIdx.x / SEQ; j0 < cnt; j0 += RS * LB) {
+        ac_c2 z[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int j = j0 + u * RS;
+            const int64_t a = off + (int64_t)(j < cnt ? j : j0) * d.row_stride;
+            if (PLANES) {
+                const unsigned h = ac_gload<unsigned>((const unsigned short *)d.rows + a);
+                const unsigned lo = ac_gload<unsigned>((const unsigned short *)d.rows_lo + a);
+                z[u] = ac_c2{ac_h2f((unsigned short)(h & 0xFFFFu)) + ac_h2f((unsigned short)(lo & 0xFFFFu)),
+                             ac_h2f((unsigned short)(h >> 16)) + ac_h2f((unsigned short)(lo >> 16))};
+            } else {
+                z[u] = ac_gload<ac_c2>((const float *)d.rows + a);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (j0 + u * RS < cnt) seq[phys(n0 + j0 + u * RS)] = z[u];
+    }
+    fft_forward<SEQ, U>(fbuf, tw, d.logn);
+    spectrum_store<SEQ, SB>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn);
+}
+
+// half spectra of the pairs (y1, y2) -> Z in the bit-reversed image; `load(f)` returns [y1.re y1.im y2.re y2.im]
+template <int SEQ, int LB, typename LOAD>
+__device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, LOAD load) {
+    const int halfn = 1 << (logn - 1);
+    constexpr int RS = FFT_THREADS / SEQ;
+    for (int idx0 = threadIdx.x / SEQ; idx0 <= halfn; idx0 += RS * LB) {
         f32x4 v[LB];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
             const int idx = idx0 + u * RS;
-            v[u] = ac_gload<f32x4>(src + (int64_t)brev(half_pos(idx <= halfn ? idx : idx0, halfn), p.logn) * fstride);
+            v[u] = load(brev(half_pos(idx <= halfn ? idx : idx0, halfn), logn));
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
@@ -210,22 +209,43 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kern
             if (i > 1) seq[phys(partner(i))] = zn;
         }
     }
-    fft_inverse<U>(fbuf, tw, p.logn);
+}
+
+template <int SEQ, int U>
+__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kernel(RowsParams p) {
+    constexpr int LB = U == 1 ? 2 : 8;
+    constexpr int RS = FFT_THREADS / SEQ;
+    extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
+    const ac_fft_rows_desc &d = p.d;
+    const int N = 1 << d.logn, pitch = seq_pitch(d.logn, SEQ);
+    int row, g;
+    map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
+    const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
+    const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
+    const TwTable tw{(const ac_c2 *)d.tw, N};
+    ac_c2 *seq = fbuf + q * pitch;
+    const float *src = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
+    const int64_t fstride = (int64_t)d.B * d.blocks * (2 * d.C);
+    spectrum_load<SEQ, LB>(seq, d.logn, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
+    fft_inverse<SEQ, U>(fbuf, tw, d.logn);
     const float inv = 1.0f / (float)N;
-    float *dst = p.dst + (int64_t)b * p.batch_stride + p.col_off + c0 + 2 * q;
+    // this block's output rows rv + j, j < cnt, = sequence index j + shift
+    int cnt = d.L - rv;
+    if (d.blocks > 1 && cnt > d.block_step) cnt = d.block_step;
+    float *dst = (float *)d.rows + (int64_t)b * d.batch_stride + (int64_t)rv * d.row_stride + d.col_off + c0 + 2 * q;
     ac_c2 bias2 = {0.f, 0.f};
-    if (p.bias) bias2 = ac_gload<ac_c2>(p.bias + c0 + 2 * q);
-    for (int l0 = threadIdx.x >> 3; l0 < p.L; l0 += RS * LB) {
+    if (d.bias) bias2 = ac_gload<ac_c2>(d.bias + c0 + 2 * q);
+    for (int j0 = threadIdx.x / SEQ; j0 < cnt; j0 += RS * LB) {
         ac_c2 o[LB];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-            const int l = l0 + u * RS < p.L ? l0 + u * RS : l0;
-            o[u] = seq[phys(l + p.shift)] * inv + bias2;
-            if (p.accumulate) o[u] += ac_gload<ac_c2>(dst + (int64_t)l * p.row_stride);
+            const int j = j0 + u * RS < cnt ? j0 + u * RS : j0;
+            o[u] = seq[phys(j + d.shift)] * inv + bias2;
+            if (d.accumulate) o[u] += ac_gload<ac_c2>(dst + (int64_t)j * d.row_stride);
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u)
-            if (l0 + u * RS < p.L) *(ac_c2 *)(dst + (int64_t)(l0 + u * RS) * p.row_stride) = o[u];
+            if (j0 + u * RS < cnt) *(ac_c2 *)(dst + (int64_t)(j0 + u * RS) * d.row_stride) = o[u];
     }
 }
 
@@ -236,27 +256,28 @@ struct TapsParams {
     int Cout, Cin, k, logn;
 };
 
-// workgroup = (co, 16 input channels): h[m] = w[co][k - 1 - m][ci], pairs of ci transformed together
-template <int U>
+// workgroup = (co, 2 SEQ input channels): h[m] = w[co][k - 1 - m][ci], pairs of ci transformed together
+template <int SEQ, int U>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kernel(TapsParams p) {
+    constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
-    const int G = p.Cin >> 4, co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 16;
-    const int q = threadIdx.x & 7;
+    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn, SEQ);
+    const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
+    const int q = threadIdx.x & (SEQ - 1);
     const TwTable tw{p.tw, N};
     ac_c2 *seq = fbuf + q * pitch;
     const float *w = p.src + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
-    for (int m = threadIdx.x >> 3; m < N; m += FFT_THREADS / 8) {
+    for (int m = threadIdx.x / SEQ; m < N; m += RS) {
         const bool in = m < p.k;
         const ac_c2 z = ac_gload<ac_c2>(w + (int64_t)(in ? p.k - 1 - m : 0) * p.Cin);
         seq[phys(m)] = in ? z : ac_c2{0.f, 0.f};
     }
-    fft_forward<U>(fbuf, tw, p.logn);
+    fft_forward<SEQ, U>(fbuf, tw, p.logn);
     // H'[f][(co, re)][(ci, re)] = Hr, [(co, re)][(ci, im)] = -Hi, [(co, im)][(ci, re)] = Hi, [(co, im)][(ci, im)] = Hr
     const int ld = 2 * p.Cin;
     float *o = p.dst + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);
     const int64_t fstride = (int64_t)(2 * p.Cout) * ld;
-    for (int idx = threadIdx.x >> 3; idx <= halfn; idx += FFT_THREADS / 8) {
+    for (int idx = threadIdx.x / SEQ; idx <= halfn; idx += RS) {
         const int i = half_pos(idx, halfn), f = brev(i, p.logn);
         ac_c2 h1, h2;
         untangle(seq[phys(i)], seq[phys(partner(i))], h1, h2);
@@ -266,40 +287,38 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kern
     }
 }
 
-// workgroup = (co, 16 input channels): conj(X_f) G_f for the pairs of ci from the rows (co, re), (co, im) of M'
-template <int U>
+// workgroup = (co, 2 SEQ input channels): conj(X_f) G_f for the pairs of ci from the rows (co, re), (co, im) of M'
+template <int SEQ, int U>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kernel(TapsParams p) {
+    constexpr int LB = U == 1 ? 1 : 4;
+    constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn);
-    const int G = p.Cin >> 4, co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 16;
-    const int q = threadIdx.x & 7;
+    const int N = 1 << p.logn, pitch = seq_pitch(p.logn, SEQ);
+    const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
+    const int q = threadIdx.x & (SEQ - 1);
     const TwTable tw{p.tw, N};
     ac_c2 *seq = fbuf + q * pitch;
     const int ld = 2 * p.Cin;
     const float *mre = p.src + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);   // row (co, re); row (co, im) = + ld
     const int64_t fstride = (int64_t)(2 * p.Cout) * ld;
-    for (int idx = threadIdx.x >> 3; idx <= halfn; idx += FFT_THREADS / 8) {
-        const int i = half_pos(idx, halfn), f = brev(i, p.logn);
-        const float *mf = mre + (int64_t)f * fstride;
+    spectrum_load<SEQ, LB>(seq, p.logn, [&](int f) {
         // r = [M'_rr(ci) M'_ri(ci) M'_rr(ci+1) M'_ri(ci+1)], m = [M'_ir M'_ii ...]
+        const float *mf = mre + (int64_t)f * fstride;
         const f32x4 r = ac_gload<f32x4>(mf), m = ac_gload<f32x4>(mf + ld);
-        ac_c2 zf, zn;
-        tangle(ac_c2{r[0] + m[1], m[0] - r[1]}, ac_c2{r[2] + m[3], m[2] - r[3]}, zf, zn);
-        seq[phys(i)] = zf;
-        if (i > 1) seq[phys(partner(i))] = zn;
-    }
-    fft_inverse<U>(fbuf, tw, p.logn);
+        return f32x4{r[0] + m[1], m[0] - r[1], r[2] + m[3], m[2] - r[3]};
+    });
+    fft_inverse<SEQ, U>(fbuf, tw, p.logn);
     const float inv = 1.0f / (float)N;
     float *dw = p.dst + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
-    for (int t = threadIdx.x >> 3; t < p.k; t += FFT_THREADS / 8) {
+    for (int t = threadIdx.x / SEQ; t < p.k; t += RS) {
         ac_c2 *d = (ac_c2 *)(dw + (int64_t)t * p.Cin);
         *d += seq[phys(p.k - 1 - t)] * inv;
     }
 }
 
 template <typename K, typename P>
-int fft_launch(K kernel, int blocks, const P &p, int logn, hipStream_t stream) {
-    const size_t lds = (size_t)FFT_SEQ * seq_pitch(logn) * sizeof(ac_c2);
+int fft_launch(K kernel, int blocks, const P &p, int logn, int nseq, hipStream_t stream) {
+    const size_t lds = (size_t)nseq * seq_pitch(logn, nseq) * sizeof(ac_c2);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
@@ -309,45 +328,63 @@ int fft_launch(K kernel, int blocks, const P &p, int logn, hipStream_t stream) {
     return AC_OK;
 }
 
-bool logn_ok(int logn) { return logn >= 6 && logn <= 11; }
+bool logn_ok(int logn) { return logn >= 5 && logn <= 11; }
+// 32 sequences (64 channels) per workgroup for the short transforms, 8 (16 channels) otherwise
+int nseq_for(int logn, int channels) { return (logn <= 7 && channels % 64 == 0) ? 32 : 8; }
+
+int rows_check(const ac_fft_rows_desc &d, bool inverse) {
+    if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !logn_ok(d.logn)) return AC_EINVAL;
+    const int N = 1 << d.logn;
+    if (d.blocks < 1 || d.shift < 0 || d.shift >= N) return AC_EINVAL;
+    if (d.blocks > 1 && (d.block_step < 1 || d.block_step > N || (int64_t)d.blocks * d.block_step < d.L)) return AC_EINVAL;
+    if (inverse) {
+        const int cnt = d.blocks > 1 ? d.block_step : d.L;
+        if (cnt + d.shift > N || d.rows_lo) return AC_EINVAL;
+    } else {
+        if (d.blocks == 1 && d.L + d.shift > N) return AC_EINVAL;       // one sequence per sample must hold every row
+        if (d.n_lo < 0 || d.n_hi > N || d.n_lo >= d.n_hi) return AC_EINVAL;
+    }
+    const uintptr_t amask = d.rows_lo ? 3u : 7u;   // one 4-byte (two bf16) or 8-byte (two fp32) access per channel pair
+    if ((d.row_stride % 2) || (d.batch_stride % 2) || (d.col_off % 2) || ((uintptr_t)d.rows & amask) ||
+        ((uintptr_t)d.rows_lo & amask) || !ac_aligned16(d.spec) || ((uintptr_t)d.tw & 7u) || ((uintptr_t)d.bias & 7u))
+        return AC_EALIGN;
+    return AC_OK;
+}
 
 }  // namespace
 
-extern "C" int ac_fft_rows_fwd(const void *src, const void *src_lo, int64_t batch_stride, int64_t row_stride,
-                               int32_t col_off, int32_t B, int32_t L, int32_t C, int32_t shift, int32_t logn,
-                               const float *tw, float *spec, ac_stream_t stream) {
-    if (!src || !tw || !spec || B <= 0 || L <= 0 || C <= 0 || (C % 16) || !logn_ok(logn)) return AC_EINVAL;
-    if (shift < 0 || L + shift > (1 << logn)) return AC_EINVAL;
-    const uintptr_t amask = src_lo ? 3u : 7u;   // one 4-byte (two bf16) or 8-byte (two fp32) load per channel pair
-    if ((row_stride % 2) || (batch_stride % 2) || (col_off % 2) || ((uintptr_t)src & amask) ||
-        ((uintptr_t)src_lo & amask) || !ac_aligned16(spec) || ((uintptr_t)tw & 7u))
-        return AC_EALIGN;
+extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
+    if (!dp) return AC_EINVAL;
     RowsParams p;
-    p.src = src; p.src_lo = src_lo; p.dst = spec; p.tw = (const ac_c2 *)tw; p.bias = nullptr;
-    p.row_stride = row_stride; p.batch_stride = batch_stride; p.col_off = col_off;
-    p.B = B; p.C = C; p.L = L; p.shift = shift; p.logn = logn; p.accumulate = 0;
-    const int blocks = B * (C / 16);
+    p.d = *dp;
+    ac_fft_rows_desc &d = p.d;
+    if (d.n_hi == 0 && d.n_lo == 0) d.n_hi = 1 << (d.logn > 0 && d.logn < 31 ? d.logn : 0);
+    const int rc = rows_check(d, false);
+    if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (src_lo) return logn >= 10 ? fft_launch(fft_rows_fwd_kernel<true, 4>, blocks, p, logn, st)
-                                  : fft_launch(fft_rows_fwd_kernel<true, 1>, blocks, p, logn, st);
-    return logn >= 10 ? fft_launch(fft_rows_fwd_kernel<false, 4>, blocks, p, logn, st)
-                      : fft_launch(fft_rows_fwd_kernel<false, 1>, blocks, p, logn, st);
+    const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    if (ns == 32)
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true>, blocks, p, d.logn, 32, st)
+                         : fft_launch(fft_rows_fwd_kernel<32, 1, false>, blocks, p, d.logn, 32, st);
+    if (d.logn >= 10)
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true>, blocks, p, d.logn, 8, st)
+                         : fft_launch(fft_rows_fwd_kernel<8, 4, false>, blocks, p, d.logn, 8, st);
+    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true>, blocks, p, d.logn, 8, st)
+                     : fft_launch(fft_rows_fwd_kernel<8, 1, false>, blocks, p, d.logn, 8, st);
 }
 
-extern "C" int ac_fft_rows_inv(const float *spec, int32_t B, int32_t C, int32_t logn, const float *tw, float *dst,
-                               int64_t batch_stride, int64_t row_stride, int32_t col_off, int32_t L, int32_t shift,
-                               const float *bias, int32_t accumulate, ac_stream_t stream) {
-    if (!spec || !tw || !dst || B <= 0 || L <= 0 || C <= 0 || (C % 16) || !logn_ok(logn)) return AC_EINVAL;
-    if (shift < 0 || L + shift > (1 << logn)) return AC_EINVAL;
-    if ((row_stride % 2) || (batch_stride % 2) || (col_off % 2) || ((uintptr_t)dst & 7u) || !ac_aligned16(spec) ||
-        ((uintptr_t)tw & 7u) || (bias && ((uintptr_t)bias & 7u)))
-        return AC_EALIGN;
+extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
+    if (!dp) return AC_EINVAL;
     RowsParams p;
-    p.src = spec; p.src_lo = nullptr; p.dst = dst; p.tw = (const ac_c2 *)tw; p.bias = bias;
-    p.row_stride = row_stride; p.batch_stride = batch_stride; p.col_off = col_off;
-    p.B = B; p.C = C; p.L = L; p.shift = shift; p.logn = logn; p.accumulate = accumulate;
-    return logn >= 10 ? fft_launch(fft_rows_inv_kernel<4>, B * (C / 16), p, logn, (hipStream_t)stream)
-                      : fft_launch(fft_rows_inv_kernel<1>, B * (C / 16), p, logn, (hipStream_t)stream);
+    p.d = *dp;
+    const ac_fft_rows_desc &d = p.d;
+    const int rc = rows_check(d, true);
+    if (rc != AC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1>, blocks, p, d.logn, 32, st);
+    if (d.logn >= 10) return fft_launch(fft_rows_inv_kernel<8, 4>, blocks, p, d.logn, 8, st);
+    return fft_launch(fft_rows_inv_kernel<8, 1>, blocks, p, d.logn, 8, st);
 }
 
 extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -357,8 +394,11 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     if (((uintptr_t)w & 7u) || !ac_aligned16(hblock) || ((uintptr_t)tw & 7u)) return AC_EALIGN;
     TapsParams p;
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
-    return logn >= 10 ? fft_launch(fft_taps_fwd_kernel<4>, Cout * (Cin / 16), p, logn, (hipStream_t)stream)
-                      : fft_launch(fft_taps_fwd_kernel<1>, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1>, blocks, p, logn, 32, st);
+    if (logn >= 10) return fft_launch(fft_taps_fwd_kernel<8, 4>, blocks, p, logn, 8, st);
+    return fft_launch(fft_taps_fwd_kernel<8, 1>, blocks, p, logn, 8, st);
 }
 
 extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -368,6 +408,9 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     if (!ac_aligned16(m) || ((uintptr_t)tw & 7u) || ((uintptr_t)dw & 7u)) return AC_EALIGN;
     TapsParams p;
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
-    return logn >= 10 ? fft_launch(fft_taps_inv_kernel<4>, Cout * (Cin / 16), p, logn, (hipStream_t)stream)
-                      : fft_launch(fft_taps_inv_kernel<1>, Cout * (Cin / 16), p, logn, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1>, blocks, p, logn, 32, st);
+    if (logn >= 10) return fft_launch(fft_taps_inv_kernel<8, 4>, blocks, p, logn, 8, st);
+    return fft_launch(fft_taps_inv_kernel<8, 1>, blocks, p, logn, 8, st);
 }

@@ -3,7 +3,7 @@
 // so that the index algebra is proven before a kernel ever runs on the GPU.
 //
 // One complex sequence of N = 2^logn points lives in a padded image: element i at phys(i) = i + (i >> 3) (one spare
-// 8-byte slot per 8 elements), sequences seq_pitch(logn) slots apart (= 4 mod 32).  With that padding every access
+// 8-byte slot per 8 elements), sequences seq_pitch(logn, nseq) slots apart.  With that padding every access
 // pattern below is (near) bank-conflict free for 8-byte LDS accesses:
 //   * passes with a large stride: the lanes of a wave walk consecutive elements;
 //   * the pass with stride 8: element blk*64 + i0 + 8m -> slot 72 blk + i0 + 9m: 4 blocks x 8 i0 = 32 distinct slots;
@@ -24,7 +24,12 @@ typedef float ac_c2 __attribute__((ext_vector_type(2)));   // (re, im)
 namespace acfft {
 
 AC_FFT_HD int phys(int i) { return i + (i >> 3); }
-AC_FFT_HD int seq_pitch(int logn) { return (1 << logn) + (1 << (logn - 3)) + 4; }
+// slots between the sequences of a workgroup: = 4 mod 32 when 8 sequences share it (lanes = 8 sequences x 4
+// consecutive elements), = 1 mod 32 when 32 do (lanes = 32 sequences): distinct banks either way
+AC_FFT_HD int seq_pitch(int logn, int nseq = 8) {
+    const int body = (1 << logn) + (1 << (logn - 3));
+    return ((body + 31) & ~31) + (nseq > 8 ? 1 : 4);
+}
 
 AC_FFT_HD ac_c2 cmul(ac_c2 a, ac_c2 w) { return ac_c2{a[0] * w[0] - a[1] * w[1], a[0] * w[1] + a[1] * w[0]}; }
 AC_FFT_HD ac_c2 conj(ac_c2 a) { return ac_c2{a[0], -a[1]}; }

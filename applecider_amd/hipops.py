@@ -1611,6 +1611,7 @@ def global_max(x):
 _FFTCONV = True       # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
 _FFT_MATH = None      # arithmetic of the per-frequency products: None = the math mode's (fp32 or split-bf16 matrix cores)
 _FFT_FORCE = False    # tests: the transform form wherever the kernels cover the shape, whatever the cost rule says
+_FFT_MARGIN = 1.2     # the direct form must cost this many times the transform form's estimate before it is replaced
 _fft_tables: dict = {}
 
 
@@ -1631,48 +1632,104 @@ def _fft_tw(logn: int, device) -> torch.Tensor:
     return t
 
 
-def fft_logn(L: int, k: int):
-    """log2 of the transform length of a 'same' Conv1d with k taps on L positions: N >= L + k // 2 (the circular
-    wrap of the k // 2 positions past either end of the linear convolution falls outside the cropped output)."""
+def fft_plan(L: int, k: int):
+    """(logn, blocks, step) of the transform form of a 'same' Conv1d with k taps on L positions.
+    blocks = 1: one sequence of N = 2^logn >= L + k // 2 points per sample (the circular wrap of the k // 2 positions
+    past either end of the linear convolution falls outside the cropped output).  blocks > 1: overlap-save — windows of
+    N points advancing by step = N - k + 1 rows; N <= 512 keeps four workgroups per CU on the transform kernels (the
+    2048-point kernel holds one), at the price of a second transform of x in the backward pass (the weight gradient
+    pairs the dy windows with x masked to each block's own rows).  None: not covered."""
+    best = None
     need = L + k // 2
-    logn = max(6, (need - 1).bit_length())
-    return logn if logn <= 11 and k <= (1 << logn) else None
+    logn1 = max(5, (need - 1).bit_length())
+    if logn1 <= 11 and k <= (1 << logn1):
+        best = ((1 << logn1) * (1.7 if logn1 >= 10 else 1.0), logn1, 1, L)
+    for logn in range(5, 10):
+        N = 1 << logn
+        V = N - k + 1
+        if V < N // 4:
+            continue
+        blocks = -(-L // V)
+        if blocks < 2:
+            continue
+        cost = blocks * N * 1.08
+        if best is None or cost < best[0]:
+            best = (cost, logn, blocks, V)
+    return None if best is None else best[1:]
+
+
+def fft_logn(L: int, k: int):
+    plan = fft_plan(L, k)
+    return None if plan is None else plan[0]
 
 
 def fftconv_covered(B: int, L: int, Cin: int, Cout: int, k: int) -> bool:
     """Whether the three products of a 'same' Conv1d run in the frequency domain.  Shape limits of the kernels, and
-    a cost rule from tools/bench_fftconv.py (profiles/r03_fftconv_kernels_*.txt): the transform form moves about
-    7 x the bytes of one (input + output) spectrum pair plus the taps' spectrum once per product at ~2.6 TB/s whatever
-    k is; the direct window kernels sustain ~500 TFLOP/s of the 6 B L Cin Cout k FLOP.  SpectraNet's default stages
-    (default_config.toml:104-114): k = 251 (12.0 -> 2.2 ms), k = 61 (3.1 -> 1.0 ms) and stage 4's k = 31 (1.7 -> 0.8 ms)
-    go through the transforms, every shorter kernel stays direct."""
+    a cost rule from tools/bench_fftconv.py (profiles/r03_fftconv_kernels_*.txt): the four (five with overlap-save)
+    transforms move rows + spectrum once each at ~3.6 TB/s (2.15 TB/s on the 1024 / 2048-point kernels), the three
+    per-frequency products their operands at ~3 TB/s or their FLOP at ~220 TFLOP/s, whatever k is; the direct window
+    kernels sustain ~480 TFLOP/s of the 6 B L Cin Cout k FLOP (~300 on the 16-position stage).  SpectraNet's default
+    stages (default_config.toml:104-114; measured fwd + both gradients, tools/bench_fftconv.py): stage 2 k = 251
+    12.5 -> 1.96 ms and k = 31 2.0 -> 1.36 ms, stage 3 k = 61 3.2 -> 1.1 ms, stage 4 k = 31 1.7 -> 0.86 ms and k = 11
+    0.81 -> 0.70 ms, stage 5 k = 13 1.1 -> 0.77 ms; every other convolution stays direct."""
     if not (_FFTCONV and _MATH in (_lib.MATH_F32, _lib.MATH_BF16X3) and _MODE != "f16" and Cin % 16 == 0
             and Cout % 16 == 0 and k % 2 == 1):
         return False
-    logn = fft_logn(L, k)
-    if logn is None:
+    plan = fft_plan(L, k)
+    if plan is None:
         return False
     if _FFT_FORCE:
         return True
-    N, F = 1 << logn, (1 << (logn - 1)) + 1
-    fft_ms = (7.0 * B * N * (Cin + Cout) * 4 + 3.0 * F * 4 * Cin * Cout * 4) / 2.6e9
-    direct_ms = 6.0 * B * L * Cin * Cout * k / 500e9
-    return direct_ms >= 1.25 * fft_ms
+    logn, blocks, _ = plan
+    pts, F = blocks << logn, (1 << (logn - 1)) + 1
+    t_bytes = (2.0 * (Cin + Cout) + (Cin if blocks > 1 else 0)) * B * 4 * (pts + L)
+    p_bytes = 3.0 * (B * pts * (Cin + Cout) * 4 + F * 4 * Cin * Cout * 4)
+    p_flops = 3.0 * F * 2 * B * blocks * 4 * Cin * Cout       # the split-bf16 product kernel sustains ~220 TFLOP/s
+    fft_ms = t_bytes / (2.15e9 if logn >= 10 else 3.6e9) + max(p_bytes / 3.0e9, p_flops / 220e9) + 0.05
+    direct_ms = 6.0 * B * L * Cin * Cout * k / (300e9 if L <= 16 else 480e9)
+    return direct_ms >= _FFT_MARGIN * fft_ms
 
 
-def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, logn) -> torch.Tensor:
-    """Spectrum [N/2 + 1, B, 2 Cn] of the channels-last rows src[b, l, col_off + c] (fp32, or (hi, lo) bf16 planes)."""
-    spec = torch.empty((1 << (logn - 1)) + 1, B, 2 * Cn, device=src.device, dtype=torch.float32)
-    _lib.check(_lib_().ac_fft_rows_fwd(_p(src, elem_off), _p(src_lo, elem_off), batch_stride, row_stride, col_off, B, L,
-                                       Cn, shift, logn, _p(_fft_tw(logn, src.device)), _p(spec), _stream()),
-               "ac_fft_rows_fwd")
+def _fft_rows_desc(rows, rows_lo, elem_off, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step,
+                   shift, n_lo, n_hi, accumulate):
+    d = _lib.FftRowsDesc()
+    d.rows, d.rows_lo, d.spec = _p(rows, elem_off), _p(rows_lo, elem_off), _p(spec)
+    d.tw, d.bias = _p(_fft_tw(logn, spec.device)), _p(bias)
+    d.batch_stride, d.row_stride, d.col_off = batch_stride, row_stride, col_off
+    d.B, d.L, d.C, d.logn = B, L, Cn, logn
+    d.blocks, d.block_step, d.shift = blocks, step, shift
+    d.n_lo, d.n_hi, d.accumulate = n_lo, n_hi, int(accumulate)
+    return d
+
+
+def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, logn, blocks=1, step=0,
+                 n_lo=0, n_hi=0) -> torch.Tensor:
+    """Spectrum [N/2 + 1, B * blocks, 2 Cn] of the channels-last rows src[b, l, col_off + c] (fp32, or (hi, lo) bf16
+    planes); row l of block r sits at sequence index l - r * step + shift (inside [n_lo, n_hi) when given)."""
+    spec = torch.empty((1 << (logn - 1)) + 1, B * blocks, 2 * Cn, device=src.device, dtype=torch.float32)
+    d = _fft_rows_desc(src, src_lo, elem_off, spec, None, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step,
+                       shift, n_lo, n_hi, 0)
+    _lib.check(_lib_().ac_fft_rows_fwd(C.byref(d), _stream()), "ac_fft_rows_fwd")
     return spec
 
 
-def fft_rows_inv(spec, B, Cn, logn, dst, batch_stride, row_stride, col_off, L, shift, bias, accumulate):
-    _lib.check(_lib_().ac_fft_rows_inv(_p(spec), B, Cn, logn, _p(_fft_tw(logn, spec.device)), _p(dst), batch_stride,
-                                       row_stride, col_off, L, shift, _p(bias), int(accumulate), _stream()),
-               "ac_fft_rows_inv")
+def fft_rows_inv(spec, B, Cn, logn, dst, batch_stride, row_stride, col_off, L, shift, bias, accumulate, blocks=1, step=0):
+    d = _fft_rows_desc(dst, None, 0, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step, shift,
+                       0, 0, accumulate)
+    _lib.check(_lib_().ac_fft_rows_inv(C.byref(d), _stream()), "ac_fft_rows_inv")
+
+
+def fft_taps_fwd(w, Cout, Cin, k, logn) -> torch.Tensor:
+    """Block spectrum [N/2 + 1, 2 Cout, 2 Cin] of the (flipped) taps w [Cout, k * Cin]."""
+    hb = torch.empty((1 << (logn - 1)) + 1, 2 * Cout, 2 * Cin, device=w.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_fft_taps_fwd(_p(w), Cout, Cin, k, logn, _p(_fft_tw(logn, w.device)), _p(hb), _stream()),
+               "ac_fft_taps_fwd")
+    return hb
+
+
+def fft_taps_inv(mp, Cout, Cin, k, logn, dw):
+    _lib.check(_lib_().ac_fft_taps_inv(_p(mp), Cout, Cin, k, logn, _p(_fft_tw(logn, mp.device)), _p(dw), _stream()),
+               "ac_fft_taps_inv")
 
 
 def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c, math=None):
@@ -1690,40 +1747,44 @@ def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c,
 def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias):
     """out[b, l, col_off + co] = bias[co] + sum_{t, ci} x[b, l + t - k//2, ci] w[co, t, ci] through the frequency
     domain (spectranet.py:18-20,25).  x [B, L, Cin] fp32 contiguous, w [Cout, k * Cin] tap-major.  Returns what the
-    gradient products reuse: (spectrum of x, block form of the taps' spectrum, logn)."""
-    logn = fft_logn(L, k)
-    F = (1 << (logn - 1)) + 1
+    gradient products reuse."""
+    logn, blocks, step = fft_plan(L, k)
+    F, p = (1 << (logn - 1)) + 1, k // 2
     dev = x.device
-    xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0, logn)
-    hb = torch.empty(F, 2 * Cout, 2 * Cin, device=dev, dtype=torch.float32)
-    _lib.check(_lib_().ac_fft_taps_fwd(_p(w), Cout, Cin, k, logn, _p(_fft_tw(logn, dev)), _p(hb), _stream()),
-               "ac_fft_taps_fwd")
-    yf = torch.empty(F, B, 2 * Cout, device=dev, dtype=torch.float32)
-    gemm_batched(AC_GEMM_NT, B, 2 * Cout, 2 * Cin, mat(_p(xf), 2 * Cin), mat(_p(hb), 2 * Cin), mat(_p(yf), 2 * Cout),
-                 F, B * 2 * Cin, 4 * Cout * Cin, B * 2 * Cout)
-    fft_rows_inv(yf, B, Cout, logn, out, L * ld_out, ld_out, col_off, L, k - 1 - k // 2, bias, False)
-    return xf, hb, logn
+    # one sequence per sample: x at shift 0, y read at k - 1 - p.  Overlap-save: windows from row r * step - p, y at k - 1
+    xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0 if blocks == 1 else p, logn, blocks, step)
+    hb = fft_taps_fwd(w, Cout, Cin, k, logn)
+    Bb = B * blocks
+    yf = torch.empty(F, Bb, 2 * Cout, device=dev, dtype=torch.float32)
+    gemm_batched(AC_GEMM_NT, Bb, 2 * Cout, 2 * Cin, mat(_p(xf), 2 * Cin), mat(_p(hb), 2 * Cin), mat(_p(yf), 2 * Cout),
+                 F, Bb * 2 * Cin, 4 * Cout * Cin, Bb * 2 * Cout)
+    fft_rows_inv(yf, B, Cout, logn, out, L * ld_out, ld_out, col_off, L, k - 1 - p if blocks == 1 else k - 1, bias, False,
+                 blocks, step)
+    # the weight gradient pairs the spectrum of dy with that of x: the same one when a sample is one sequence; with
+    # overlap-save x masked to each block's own rows, transformed in the backward pass from x itself
+    return (xf if blocks == 1 else x), hb, (logn, blocks, step)
 
 
 def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cin, Cout, k,
                      dx, dx_accumulate, dw):
     """Gradient products of fftconv_forward: dx [B, L, Cin] (nullable; stored or accumulated) and dw [Cout, k * Cin]
     (accumulated into).  dy: fp32 rows, or (dy, dy_lo) bf16 planes."""
-    xf, hb, logn = saved
-    F = (1 << (logn - 1)) + 1
-    dev = xf.device
-    gf = fft_rows_fwd(dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cout, k - 1 - k // 2, logn)
+    xs, hb, (logn, blocks, step) = saved
+    F, p = (1 << (logn - 1)) + 1, k // 2
+    dev, Bb = hb.device, B * blocks
+    gf = fft_rows_fwd(dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cout,
+                      k - 1 - p if blocks == 1 else p, logn, blocks, step)
     if dx is not None:
-        dxf = torch.empty(F, B, 2 * Cin, device=dev, dtype=torch.float32)
-        gemm_batched(AC_GEMM_NN, B, 2 * Cin, 2 * Cout, mat(_p(gf), 2 * Cout), mat(_p(hb), 2 * Cin), mat(_p(dxf), 2 * Cin),
-                     F, B * 2 * Cout, 4 * Cout * Cin, B * 2 * Cin)
-        fft_rows_inv(dxf, B, Cin, logn, dx, L * Cin, Cin, 0, L, 0, None, dx_accumulate)
+        dxf = torch.empty(F, Bb, 2 * Cin, device=dev, dtype=torch.float32)
+        gemm_batched(AC_GEMM_NN, Bb, 2 * Cin, 2 * Cout, mat(_p(gf), 2 * Cout), mat(_p(hb), 2 * Cin), mat(_p(dxf), 2 * Cin),
+                     F, Bb * 2 * Cout, 4 * Cout * Cin, Bb * 2 * Cin)
+        fft_rows_inv(dxf, B, Cin, logn, dx, L * Cin, Cin, 0, L, 0, None, dx_accumulate, blocks, step)
     if dw is not None:
+        xf = xs if blocks == 1 else fft_rows_fwd(xs, None, 0, L * Cin, Cin, 0, B, L, Cin, 0, logn, blocks, step, 0, step)
         mp = torch.empty(F, 2 * Cout, 2 * Cin, device=dev, dtype=torch.float32)
-        gemm_batched(AC_GEMM_TN, 2 * Cout, 2 * Cin, B, mat(_p(gf), 2 * Cout), mat(_p(xf), 2 * Cin), mat(_p(mp), 2 * Cin),
-                     F, B * 2 * Cout, B * 2 * Cin, 4 * Cout * Cin)
-        _lib.check(_lib_().ac_fft_taps_inv(_p(mp), Cout, Cin, k, logn, _p(_fft_tw(logn, dev)), _p(dw), _stream()),
-                   "ac_fft_taps_inv")
+        gemm_batched(AC_GEMM_TN, 2 * Cout, 2 * Cin, Bb, mat(_p(gf), 2 * Cout), mat(_p(xf), 2 * Cin), mat(_p(mp), 2 * Cin),
+                     F, Bb * 2 * Cout, Bb * 2 * Cin, 4 * Cout * Cin)
+        fft_taps_inv(mp, Cout, Cin, k, logn, dw)
 
 
 def _pad_rows(x, B, L, Cn, pad_lo, Lp):

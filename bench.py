@@ -149,6 +149,45 @@ class KernelTimer:
             return ok
         H.conv_wgrad = timed
 
+    def wrap_fft(self, H):
+        """Frequency-domain conv products (ac_fft.hip + ac_gemm_batched): transforms are rated on the bytes of the
+        real rows + the spectrum they read / write once, the per-frequency products on operands + output once."""
+        def bracket(name, orig, work):
+            def timed(*a, **kw):
+                if not self.enabled:
+                    return orig(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig(*a, **kw)
+                e.record()
+                fl, by = work(*a, **kw)
+                self.records.setdefault(name, []).append((s, e, fl, by))
+                return r
+            return timed
+
+        def spec_bytes(B, Cn, logn, blocks=1):
+            return 4.0 * ((1 << (logn - 1)) + 1) * B * blocks * 2 * Cn
+
+        H.fft_rows_fwd = bracket("fft_rows", H.fft_rows_fwd,
+                                 lambda src, lo, eo, bs, rs, co, B, L, Cn, sh, logn, blocks=1, *r:
+                                 (0.0, 4.0 * B * L * Cn + spec_bytes(B, Cn, logn, blocks)))
+        H.fft_rows_inv = bracket("fft_rows", H.fft_rows_inv,
+                                 lambda spec, B, Cn, logn, dst, bs, rs, co, L, sh, bias, acc, blocks=1, *r:
+                                 (0.0, 4.0 * B * L * Cn * (2 if acc else 1) + spec_bytes(B, Cn, logn, blocks)))
+        H.fft_taps_fwd = bracket("fft_taps", H.fft_taps_fwd,
+                                 lambda w, Cout, Cin, k, logn: (0.0, 4.0 * Cout * Cin * k + spec_bytes(2 * Cout, Cin, logn)))
+        H.fft_taps_inv = bracket("fft_taps", H.fft_taps_inv,
+                                 lambda mp, Cout, Cin, k, logn, dw: (0.0, 8.0 * Cout * Cin * k + spec_bytes(2 * Cout, Cin, logn)))
+        # whole convolutions (outer brackets over the launches above): the FLOP of the direct form they replace
+        H.fftconv_forward = bracket("freqconv", H.fftconv_forward,
+                                    lambda x, w, B, L, Cin, Cout, k, *r: (2.0 * B * L * Cin * Cout * k, 0.0))
+        H.fftconv_backward = bracket("freqconv", H.fftconv_backward,
+                                     lambda saved, dy, lo, eo, bs, rs, co, B, L, Cin, Cout, k, dx, acc, dw:
+                                     (2.0 * B * L * Cin * Cout * k * ((dx is not None) + (dw is not None)), 0.0))
+        H.gemm_batched = bracket("fft_prod", H.gemm_batched,
+                                 lambda mode, M, N, K, a, b, c, batch, *r, **kw:
+                                 (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N)))
+
     def wrap_dwconv(self, H):
         lib = H._lib_()
         orig = lib.ac_dwconv7x7_fwd
@@ -561,6 +600,7 @@ def main():
     timer.wrap_gemm(H)
     timer.wrap_conv_window(H)
     timer.wrap_conv_wgrad(H)
+    timer.wrap_fft(H)
     timer.wrap_dwconv(H)
 
     for _ in range(args.warmup):
@@ -687,9 +727,11 @@ def main():
     ks = timer.summary(peak * 1e12, HBM_PEAK_GBS * 1e9)
     timed_steps, args_steps_saved = args.steps, args.steps
     args.steps = roof_steps   # the per-step figures below refer to the roofline pass
-    gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d")}
+    gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft")}
     kernel_of = {"conv1d_window": "conv1d_window_x3_kernel" if args.math == "bf16x3" else "conv1d_window_kernel",
-                 "conv1d_wgrad": "conv1d_wgrad_kernel"}
+                 "conv1d_wgrad": "conv1d_wgrad_kernel", "fft_rows": "fft_rows_fwd_kernel / fft_rows_inv_kernel",
+                 "fft_taps": "fft_taps_fwd_kernel / fft_taps_inv_kernel",
+                 "fft_prod": "gemm_x3_kernel<batched>" if args.math == "bf16x3" else "gemm_f32_kernel<batched>"}
     # dominant kernel = the family with the largest summed launch time; inside it every launch is
     # rated against the roof that bounds ITS shape, and the class that holds more of the family's
     # time is reported as `roofline` (the other class is listed beside it)
@@ -766,7 +808,7 @@ def main():
     if ran_pass and args.events_in_timed_region:
         roofline["timed_region_overlapped"] = {
             k: {"launches": v["launches"], "sum_of_launch_ms_per_step": round(v["ms"] / timed_steps, 3)}
-            for k, v in ks_timed.items() if k.startswith("gemm") or k.startswith("conv1d")}
+            for k, v in ks_timed.items() if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft")}
     out = {
         "metric": "multimodal samples/sec/GPU (fwd+bwd) at batch 512; 1->8 GPU scaling",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",
@@ -784,6 +826,16 @@ def main():
                    "encoder_streams": 3 if model.branch_streams else 1},
         "roofline": roofline,
     }
+    if "freqconv" in ks:
+        d = ks["freqconv"]
+        out["frequency_domain_convs"] = {
+            "what": "SpectraNet's long-tap Conv1d products (k = 251, 61 and stage 4's k = 31: forward, input gradient, "
+                    "weight gradient) computed as rfft -> per-frequency product -> irfft (ac_fft.hip, ac_gemm_batched)",
+            "calls_per_step": d["launches"] // roof_steps, "ms_per_step": round(d["ms"] / roof_steps, 3),
+            "direct_form_TFLOP_per_step": round(d["flops"] / roof_steps / 1e12, 3),
+            "direct_form_equivalent_TFLOPs": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
+            "note": "rate at which the direct implicit-GEMM form would have to run to match (its measured rate on the "
+                    "window kernels: ~520 TFLOP/s algorithmic); the transforms themselves are HBM-bound, see all_gemm.fft_*"}
     if fast is not None:
         out["fast_mode"] = fast
     if hip_graph_legs is not None:

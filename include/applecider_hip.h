@@ -595,24 +595,38 @@ int ac_ceil_mfma(const void *ops, float *out, int32_t shape, int32_t workgroups,
  *   AC_MATH_BF16X3, split_k = 1, 16-byte aligned operands (the matrix-core kernels; AC_EINVAL otherwise).
  * Twiddle table `tw`, provided by the caller (the library never allocates): N - 1 complex (2 floats each) entries,
  *   level e (0 <= e < logn) holds exp(-2 pi i j / (N >> e)), j < N >> (e + 1), at element offset N - (N >> e).
- * ac_fft_rows_fwd: rows src[b, l, col_off + c] (element at b * batch_stride + l * row_stride + col_off + c; fp32, or —
- *   src_lo non-null — a (hi, lo) bf16 plane pair of the same strides whose sum is the value), l < L, c < C, placed at
- *   sequence index l + shift of a zero-filled length-N sequence -> spec [N/2 + 1][B][2C].  C % 16 == 0, 6 <= logn <= 11.
- * ac_fft_rows_inv: the inverse, scaled by 1/N: dst[b, l, col_off + c] (+)= seq[l + shift] + bias[c] (bias nullable).
+ * ac_fft_rows_fwd: every sample becomes `blocks` zero-filled length-N sequences; in block r the row
+ *   rows[b, l, col_off + c] (element at b * batch_stride + l * row_stride + col_off + c; fp32, or — rows_lo non-null — a
+ *   (hi, lo) bf16 plane pair of the same strides whose sum is the value), l < L, c < C, sits at sequence index
+ *   n = l - r * block_step + shift when 0 <= n < N and n_lo <= n < n_hi (n_lo = n_hi = 0: no mask)
+ *   -> spec [N/2 + 1][B * blocks][2C], spectrum row b * blocks + r.  C % 16 == 0, 5 <= logn <= 11.
+ *   blocks = 1: one sequence per sample (L + shift <= N).  blocks > 1: overlap-save windows advancing by block_step.
+ * ac_fft_rows_inv: the inverse, scaled by 1/N: rows[b, r * block_step + j, col_off + c] (+)= seq_r[j + shift] + bias[c]
+ *   for j < block_step (blocks > 1; j < L for blocks = 1) and r * block_step + j < L; bias nullable; fp32 rows only.
  * ac_fft_taps_fwd: taps w[co][t][ci] -> hblock [N/2 + 1][2 Cout][2 Cin], the real block form [[Hr, -Hi], [Hi, Hr]]
- *   of the spectrum of h[m] = w[co][k - 1 - m][ci]: y = x * h at sequence offset k - 1 - k/2 is the 'same' correlation
- *   of nn.Conv1d.  Forward product: NT with A = spectrum of x, B = hblock; input gradient: NN with A = spectrum of dy
- *   (rows placed at shift k - 1 - k/2), B = hblock.  Cin % 16 == 0.
- * ac_fft_taps_inv: m [N/2 + 1][2 Cout][2 Cin] = (spectrum of dy)^T (spectrum of x) per frequency (TN product)
+ *   of the spectrum of h[m] = w[co][k - 1 - m][ci].  One sequence per sample: x at shift 0, y = x * h read at shift
+ *   k - 1 - k/2 is the 'same' correlation of nn.Conv1d (N >= L + k/2).  Overlap-save (block_step = N - k + 1): x windows
+ *   at shift k/2, y read at shift k - 1.  Forward product: NT with A = spectrum of x, B = hblock; input gradient: NN
+ *   with A = spectrum of dy (same placement as y), B = hblock, dx read at shift 0.  Cin % 16 == 0.
+ * ac_fft_taps_inv: m [N/2 + 1][2 Cout][2 Cin] = (spectrum of dy)^T (spectrum of x) per frequency (TN product; overlap-
+ *   save: x masked to the block's own block_step rows at shift 0, n_hi = block_step)
  *   -> dw[co][t][ci] += the weight gradient (dw is accumulated into: zero it or pass the gradient sink).
  * ---------------------------------------------------------------------- */
+typedef struct ac_fft_rows_desc {
+    const void *rows;    /* the real tensor (forward: source; inverse: destination, written through this pointer) */
+    const void *rows_lo; /* forward only, nullable: lo plane (rows = hi plane), both bf16 */
+    float *spec;         /* spectrum [N/2 + 1][B * blocks][2C] */
+    const float *tw;
+    const float *bias;   /* inverse only, nullable */
+    int64_t batch_stride, row_stride;
+    int32_t col_off, B, L, C, logn;
+    int32_t blocks, block_step, shift;
+    int32_t n_lo, n_hi;  /* forward only */
+    int32_t accumulate;  /* inverse only: rows += */
+} ac_fft_rows_desc;
 int ac_gemm_batched(const ac_gemm_desc *d, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c, ac_stream_t stream);
-int ac_fft_rows_fwd(const void *src, const void *src_lo, int64_t batch_stride, int64_t row_stride, int32_t col_off,
-                    int32_t B, int32_t L, int32_t C, int32_t shift, int32_t logn, const float *tw, float *spec,
-                    ac_stream_t stream);
-int ac_fft_rows_inv(const float *spec, int32_t B, int32_t C, int32_t logn, const float *tw, float *dst,
-                    int64_t batch_stride, int64_t row_stride, int32_t col_off, int32_t L, int32_t shift,
-                    const float *bias, int32_t accumulate, ac_stream_t stream);
+int ac_fft_rows_fwd(const ac_fft_rows_desc *d, ac_stream_t stream);
+int ac_fft_rows_inv(const ac_fft_rows_desc *d, ac_stream_t stream);
 int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
                     float *hblock, ac_stream_t stream);
 int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw, float *dw,

@@ -44,7 +44,7 @@ static void inverse(ac_c2 *seq, const std::vector<ac_c2> &tw, int logn) {
 
 int main() {
     double worst = 0.0;
-    for (int logn = 6; logn <= 11; ++logn) {
+    for (int logn = 3; logn <= 11; ++logn) {
         const int N = 1 << logn;
         const auto tw = table(logn);
         std::vector<double> x1(N), x2(N);

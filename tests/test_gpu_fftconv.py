@@ -57,14 +57,21 @@ def _ref_conv(x, w, b, dy, k):
     return y.permute(0, 2, 1), gx.permute(0, 2, 1), gw.permute(0, 2, 1).reshape(Cout, k * Cin)
 
 
-@pytest.mark.parametrize("B,L,Cin,Cout,k", [(4, 1024, 64, 128, 251),     # SpectraNet stage 2 (N = 2048)
-                                            (4, 256, 128, 256, 61),      # stage 3 (N = 512)
-                                            (8, 64, 256, 512, 31),       # stage 4 (N = 128)
+@pytest.mark.parametrize("B,L,Cin,Cout,k", [(4, 1024, 64, 128, 251),     # SpectraNet stage 2: 4 windows of 512
+                                            (2, 1024, 64, 128, 31),      # stage 2: 5 windows of 256
+                                            (4, 256, 128, 256, 61),      # stage 3: one sequence of 512
+                                            (4, 256, 128, 256, 15),      # stage 3: 6 windows of 64, 64-channel groups
+                                            (8, 64, 256, 512, 31),       # stage 4: one sequence of 128
+                                            (8, 64, 256, 512, 11),       # stage 4: 3 windows of 32
+                                            (8, 16, 512, 1024, 13),      # stage 5: one sequence of 32
+                                            (2, 900, 16, 32, 601),       # one sequence of 2048 (the 148 KB kernels)
                                             (3, 128, 16, 48, 99),        # odd batch, N = 256, 16-channel groups
+                                            (3, 100, 16, 32, 21),        # 3 windows of 64, the last one partial
                                             (2, 40, 32, 16, 49)])        # L not a power of two, N = 64
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
 def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
     from applecider_amd import _lib, hipops as H
+    assert H.fft_plan(L, k) is not None
     g = torch.Generator().manual_seed(k + L)
     x = torch.randn(B, L, Cin, generator=g)
     w = torch.randn(Cout, k * Cin, generator=g) / (k * Cin) ** 0.5
@@ -99,15 +106,27 @@ def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
         H._FFT_MATH = old
 
 
-def test_fft_entry_points_refuse_bad_shapes(dev):
+def test_fft_plan_and_refusals(dev):
     from applecider_amd import _lib, hipops as H
+    # plans of the default SpectraNet stages (default_config.toml:104-114): (logn, blocks, rows a block advances)
+    assert H.fft_plan(1024, 251) == (9, 4, 262) and H.fft_plan(1024, 31) == (8, 5, 226)
+    assert H.fft_plan(256, 61) == (9, 1, 256) and H.fft_plan(64, 31) == (7, 1, 64) and H.fft_plan(16, 13) == (5, 1, 16)
+    assert H.fft_plan(4096, 1021) is None and H.fft_logn(900, 601) == 11
     lib = _lib.load()
-    z = torch.zeros(4096, device=dev)
-    tw = H._fft_tw(6, dev)
+    z = torch.zeros(8192, device=dev)
     s = H._stream()
-    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 4, 8, 0, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL     # C % 16
-    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 60, 16, 8, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL   # L + shift > N
-    assert lib.ac_fft_rows_fwd(H._p(z), None, 64, 16, 0, 1, 4, 16, 0, 12, H._p(tw), H._p(z), s) == _lib.AC_EINVAL   # logn > 11
-    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL                      # k > N
-    assert H.fft_logn(1024, 251) == 11 and H.fft_logn(256, 61) == 9 and H.fft_logn(64, 31) == 7
-    assert H.fft_logn(4096, 1021) is None
+
+    def desc(**kw):
+        base = dict(rows=z, rows_lo=None, elem_off=0, spec=z, bias=None, batch_stride=64, row_stride=16, col_off=0, B=1, L=4,
+                    Cn=16, logn=6, blocks=1, step=0, shift=0, n_lo=0, n_hi=0, accumulate=0)
+        base.update(kw)
+        return H._fft_rows_desc(**base)
+    import ctypes as C
+    assert lib.ac_fft_rows_fwd(C.byref(desc()), s) == 0
+    assert lib.ac_fft_rows_fwd(C.byref(desc(Cn=8)), s) == _lib.AC_EINVAL                    # C % 16
+    assert lib.ac_fft_rows_fwd(C.byref(desc(L=60, shift=8)), s) == _lib.AC_EINVAL           # L + shift > N, one sequence
+    assert lib.ac_fft_rows_fwd(C.byref(desc(L=4, blocks=2, step=1)), s) == _lib.AC_EINVAL   # blocks do not cover L
+    assert lib.ac_fft_rows_inv(C.byref(desc(L=4, blocks=2, step=62, shift=8)), s) == _lib.AC_EINVAL   # step + shift > N
+    tw = H._fft_tw(6, dev)
+    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL       # k > N
+    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 5, 12, H._p(tw), H._p(z), s) == _lib.AC_EINVAL       # logn > 11
