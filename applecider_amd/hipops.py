@@ -1608,11 +1608,15 @@ def global_max(x):
 
 
 # --------------------------------------------------------------------------- frequency-domain conv products
-_FFTCONV = True       # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
+import os as _os
+_FFTCONV = not _os.environ.get("APPLECIDER_NO_FFTCONV")   # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
 _FFT_MATH = None      # arithmetic of the per-frequency products: None = the math mode's (fp32 or split-bf16 matrix cores)
 _FFT_FORCE = False    # tests: the transform form wherever the kernels cover the shape, whatever the cost rule says
 _FFT_MARGIN = 1.2     # the direct form must cost this many times the transform form's estimate before it is replaced
 _fft_tables: dict = {}
+
+
+_FFT_OVERLAP_SAVE = not _os.environ.get("APPLECIDER_FFT_NO_OVERLAP_SAVE")   # A/B: one sequence per sample only
 
 
 def _fft_tw(logn: int, device) -> torch.Tensor:
@@ -1643,8 +1647,10 @@ def fft_plan(L: int, k: int):
     need = L + k // 2
     logn1 = max(5, (need - 1).bit_length())
     if logn1 <= 11 and k <= (1 << logn1):
-        best = ((1 << logn1) * (1.7 if logn1 >= 10 else 1.0), logn1, 1, L)
-    for logn in range(5, 10):
+        # (measured, tools/bench_fftconv.py: stage 2's k = 251 costs the same as one 2048-point sequence, 1.91 ms, and
+        # as four 512-point windows, 1.96 ms — the window form needs a fifth transform; the sequence form is kept)
+        best = (float(1 << logn1), logn1, 1, L)
+    for logn in range(5, 10 if _FFT_OVERLAP_SAVE else 5):
         N = 1 << logn
         V = N - k + 1
         if V < N // 4:

@@ -57,7 +57,8 @@ def _ref_conv(x, w, b, dy, k):
     return y.permute(0, 2, 1), gx.permute(0, 2, 1), gw.permute(0, 2, 1).reshape(Cout, k * Cin)
 
 
-@pytest.mark.parametrize("B,L,Cin,Cout,k", [(4, 1024, 64, 128, 251),     # SpectraNet stage 2: 4 windows of 512
+@pytest.mark.parametrize("B,L,Cin,Cout,k", [(4, 1024, 64, 128, 251),     # SpectraNet stage 2: one sequence of 2048
+                                            (2, 1024, 64, 128, 129),     # 3 windows of 512
                                             (2, 1024, 64, 128, 31),      # stage 2: 5 windows of 256
                                             (4, 256, 128, 256, 61),      # stage 3: one sequence of 512
                                             (4, 256, 128, 256, 15),      # stage 3: 6 windows of 64, 64-channel groups
@@ -109,7 +110,7 @@ def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
 def test_fft_plan_and_refusals(dev):
     from applecider_amd import _lib, hipops as H
     # plans of the default SpectraNet stages (default_config.toml:104-114): (logn, blocks, rows a block advances)
-    assert H.fft_plan(1024, 251) == (9, 4, 262) and H.fft_plan(1024, 31) == (8, 5, 226)
+    assert H.fft_plan(1024, 251) == (11, 1, 1024) and H.fft_plan(1024, 31) == (8, 5, 226)
     assert H.fft_plan(256, 61) == (9, 1, 256) and H.fft_plan(64, 31) == (7, 1, 64) and H.fft_plan(16, 13) == (5, 1, 16)
     assert H.fft_plan(4096, 1021) is None and H.fft_logn(900, 601) == 11
     lib = _lib.load()
