@@ -29,7 +29,6 @@ namespace {
 using namespace acfft;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FFT_THREADS = 512;
 
 struct TwTable {
     const ac_c2 *tw;   // all levels back to back: level e (transform size N >> e) at element N - (N >> e)
@@ -42,7 +41,7 @@ struct TwTable {
 // waves per SIMD, so nothing else hides those latencies).
 // Kernels come in two register budgets: U = 4 (N >= 1024: LDS admits one or two workgroups per CU anyway) and
 // U = 1 (N <= 512: ~52 VGPRs, four workgroups per CU hide the latencies between them).
-template <int R, bool INVERSE, int SEQ, int PASS_U>
+template <int R, bool INVERSE, int SEQ, int PASS_U, int FFT_THREADS>
 __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int arg) {
     const int per = 1 << (logn - R), pitch = seq_pitch(logn, SEQ), total = SEQ * per;
     __syncthreads();
@@ -77,22 +76,22 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
 }
 
 // natural order in -> bit-reversed order out
-template <int SEQ, int U>
+template <int SEQ, int U, int NT>
 __device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
-    if (r0 == 1) fft_pass_all<1, false, SEQ, U>(buf, tw, logn, 0);
-    if (r0 == 2) fft_pass_all<2, false, SEQ, U>(buf, tw, logn, 0);
-    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U>(buf, tw, logn, s);
+    if (r0 == 1) fft_pass_all<1, false, SEQ, U, NT>(buf, tw, logn, 0);
+    if (r0 == 2) fft_pass_all<2, false, SEQ, U, NT>(buf, tw, logn, 0);
+    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U, NT>(buf, tw, logn, s);
     __syncthreads();
 }
 // bit-reversed order in -> natural order out (unnormalised inverse)
-template <int SEQ, int U>
+template <int SEQ, int U, int NT>
 __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int logn) {
     const int r0 = first_r(logn);
     int lh = 0;
-    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U>(buf, tw, logn, lh);
-    if (r0 == 1) fft_pass_all<1, true, SEQ, U>(buf, tw, logn, lh);
-    if (r0 == 2) fft_pass_all<2, true, SEQ, U>(buf, tw, logn, lh);
+    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U, NT>(buf, tw, logn, lh);
+    if (r0 == 1) fft_pass_all<1, true, SEQ, U, NT>(buf, tw, logn, lh);
+    if (r0 == 2) fft_pass_all<2, true, SEQ, U, NT>(buf, tw, logn, lh);
     __syncthreads();
 }
 
@@ -117,7 +116,7 @@ struct RowsParams {
 };
 
 // LDS image <-> spectrum [F][rows][2C]: every lane moves one (frequency, channel pair) = 16 bytes
-template <int SEQ, int SB>
+template <int SEQ, int SB, int FFT_THREADS>
 __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int64_t fstride, int logn) {
     const int halfn = 1 << (logn - 1);
     constexpr int RS = FFT_THREADS / SEQ;
@@ -140,7 +139,7 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
     }
 }
 
-template <int SEQ, int U, bool PLANES>
+template <int SEQ, int U, bool PLANES, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kernel(RowsParams p) {
     constexpr int LB = U == 1 ? 2 : 8, SB = U == 1 ? 2 : 4;     // global loads / LDS reads in flight per thread
     constexpr int RS = FFT_THREADS / SEQ;                        // rows per sweep of the workgroup
@@ -182,12 +181,12 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
         for (int u = 0; u < LB; ++u)
             if (j0 + u * RS < cnt) seq[phys(n0 + j0 + u * RS)] = z[u];
     }
-    fft_forward<SEQ, U>(fbuf, tw, d.logn);
-    spectrum_store<SEQ, SB>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn);
+    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn);
+    spectrum_store<SEQ, SB, FFT_THREADS>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn);
 }
 
 // half spectra of the pairs (y1, y2) -> Z in the bit-reversed image; `load(f)` returns [y1.re y1.im y2.re y2.im]
-template <int SEQ, int LB, typename LOAD>
+template <int SEQ, int LB, int FFT_THREADS, typename LOAD>
 __device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, LOAD load) {
     const int halfn = 1 << (logn - 1);
     constexpr int RS = FFT_THREADS / SEQ;
@@ -211,7 +210,7 @@ __device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, LOAD load) {
     }
 }
 
-template <int SEQ, int U>
+template <int SEQ, int U, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kernel(RowsParams p) {
     constexpr int LB = U == 1 ? 2 : 8;
     constexpr int RS = FFT_THREADS / SEQ;
@@ -226,8 +225,8 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kern
     ac_c2 *seq = fbuf + q * pitch;
     const float *src = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
     const int64_t fstride = (int64_t)d.B * d.blocks * (2 * d.C);
-    spectrum_load<SEQ, LB>(seq, d.logn, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
-    fft_inverse<SEQ, U>(fbuf, tw, d.logn);
+    spectrum_load<SEQ, LB, FFT_THREADS>(seq, d.logn, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
+    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn);
     const float inv = 1.0f / (float)N;
     // this block's output rows rv + j, j < cnt, = sequence index j + shift
     int cnt = d.L - rv;
@@ -257,7 +256,7 @@ struct TapsParams {
 };
 
 // workgroup = (co, 2 SEQ input channels): h[m] = w[co][k - 1 - m][ci], pairs of ci transformed together
-template <int SEQ, int U>
+template <int SEQ, int U, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kernel(TapsParams p) {
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kern
         const ac_c2 z = ac_gload<ac_c2>(w + (int64_t)(in ? p.k - 1 - m : 0) * p.Cin);
         seq[phys(m)] = in ? z : ac_c2{0.f, 0.f};
     }
-    fft_forward<SEQ, U>(fbuf, tw, p.logn);
+    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn);
     // H'[f][(co, re)][(ci, re)] = Hr, [(co, re)][(ci, im)] = -Hi, [(co, im)][(ci, re)] = Hi, [(co, im)][(ci, im)] = Hr
     const int ld = 2 * p.Cin;
     float *o = p.dst + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kern
 }
 
 // workgroup = (co, 2 SEQ input channels): conj(X_f) G_f for the pairs of ci from the rows (co, re), (co, im) of M'
-template <int SEQ, int U>
+template <int SEQ, int U, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kernel(TapsParams p) {
     constexpr int LB = U == 1 ? 1 : 4;
     constexpr int RS = FFT_THREADS / SEQ;
@@ -301,13 +300,13 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
     const int ld = 2 * p.Cin;
     const float *mre = p.src + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);   // row (co, re); row (co, im) = + ld
     const int64_t fstride = (int64_t)(2 * p.Cout) * ld;
-    spectrum_load<SEQ, LB>(seq, p.logn, [&](int f) {
+    spectrum_load<SEQ, LB, FFT_THREADS>(seq, p.logn, [&](int f) {
         // r = [M'_rr(ci) M'_ri(ci) M'_rr(ci+1) M'_ri(ci+1)], m = [M'_ir M'_ii ...]
         const float *mf = mre + (int64_t)f * fstride;
         const f32x4 r = ac_gload<f32x4>(mf), m = ac_gload<f32x4>(mf + ld);
         return f32x4{r[0] + m[1], m[0] - r[1], r[2] + m[3], m[2] - r[3]};
     });
-    fft_inverse<SEQ, U>(fbuf, tw, p.logn);
+    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn);
     const float inv = 1.0f / (float)N;
     float *dw = p.dst + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
     for (int t = threadIdx.x / SEQ; t < p.k; t += RS) {
@@ -318,6 +317,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
 
 template <typename K, typename P>
 int fft_launch(K kernel, int blocks, const P &p, int logn, int nseq, hipStream_t stream) {
+    const int FFT_THREADS = nseq == 4 ? 256 : 512;
     const size_t lds = (size_t)nseq * seq_pitch(logn, nseq) * sizeof(ac_c2);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -329,7 +329,10 @@ int fft_launch(K kernel, int blocks, const P &p, int logn, int nseq, hipStream_t
 }
 
 bool logn_ok(int logn) { return logn >= 5 && logn <= 11; }
-// 32 sequences (64 channels) per workgroup for the short transforms, 8 (16 channels) otherwise
+// sequences per workgroup: 32 (64 channels) for the short transforms, 8 (16 channels) otherwise.  Measured and
+// dropped for N = 2048: 4 sequences per 256-thread workgroup (74 KB of LDS, two workgroups per CU so that one loads /
+// stores while the other transforms) — the 32-byte row segments cost more than the overlap returns: stage 2's k = 251
+// convolution 2.27 ms against 1.96 ms (tools/bench_fftconv.py).
 int nseq_for(int logn, int channels) { return (logn <= 7 && channels % 64 == 0) ? 32 : 8; }
 
 int rows_check(const ac_fft_rows_desc &d, bool inverse) {
@@ -364,13 +367,13 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
     if (ns == 32)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true>, blocks, p, d.logn, 32, st)
-                         : fft_launch(fft_rows_fwd_kernel<32, 1, false>, blocks, p, d.logn, 32, st);
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 512>, blocks, p, d.logn, 32, st)
+                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 512>, blocks, p, d.logn, 32, st);
     if (d.logn >= 10)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true>, blocks, p, d.logn, 8, st)
-                         : fft_launch(fft_rows_fwd_kernel<8, 4, false>, blocks, p, d.logn, 8, st);
-    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true>, blocks, p, d.logn, 8, st)
-                     : fft_launch(fft_rows_fwd_kernel<8, 1, false>, blocks, p, d.logn, 8, st);
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, d.logn, 8, st)
+                         : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, d.logn, 8, st);
+    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 512>, blocks, p, d.logn, 8, st)
+                     : fft_launch(fft_rows_fwd_kernel<8, 1, false, 512>, blocks, p, d.logn, 8, st);
 }
 
 extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
@@ -382,9 +385,9 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
-    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1>, blocks, p, d.logn, 32, st);
-    if (d.logn >= 10) return fft_launch(fft_rows_inv_kernel<8, 4>, blocks, p, d.logn, 8, st);
-    return fft_launch(fft_rows_inv_kernel<8, 1>, blocks, p, d.logn, 8, st);
+    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 512>, blocks, p, d.logn, 32, st);
+    if (d.logn >= 10) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, d.logn, 8, st);
+    return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, d.logn, 8, st);
 }
 
 extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -396,9 +399,9 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
     hipStream_t st = (hipStream_t)stream;
     const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1>, blocks, p, logn, 32, st);
-    if (logn >= 10) return fft_launch(fft_taps_fwd_kernel<8, 4>, blocks, p, logn, 8, st);
-    return fft_launch(fft_taps_fwd_kernel<8, 1>, blocks, p, logn, 8, st);
+    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 512>, blocks, p, logn, 32, st);
+    if (logn >= 10) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, logn, 8, st);
+    return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, logn, 8, st);
 }
 
 extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
@@ -410,7 +413,7 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
     hipStream_t st = (hipStream_t)stream;
     const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1>, blocks, p, logn, 32, st);
-    if (logn >= 10) return fft_launch(fft_taps_inv_kernel<8, 4>, blocks, p, logn, 8, st);
-    return fft_launch(fft_taps_inv_kernel<8, 1>, blocks, p, logn, 8, st);
+    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 512>, blocks, p, logn, 32, st);
+    if (logn >= 10) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, logn, 8, st);
+    return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, logn, 8, st);
 }

@@ -25,10 +25,10 @@ namespace acfft {
 
 AC_FFT_HD int phys(int i) { return i + (i >> 3); }
 // slots between the sequences of a workgroup: = 4 mod 32 when 8 sequences share it (lanes = 8 sequences x 4
-// consecutive elements), = 1 mod 32 when 32 do (lanes = 32 sequences): distinct banks either way
+// consecutive elements), = 8 mod 32 for 4 sequences (x 8 elements), = 1 mod 32 for 32 sequences: distinct banks
 AC_FFT_HD int seq_pitch(int logn, int nseq = 8) {
     const int body = (1 << logn) + (1 << (logn - 3));
-    return ((body + 31) & ~31) + (nseq > 8 ? 1 : 4);
+    return ((body + 31) & ~31) + (nseq > 8 ? 1 : nseq == 4 ? 8 : 4);
 }
 
 AC_FFT_HD ac_c2 cmul(ac_c2 a, ac_c2 w) { return ac_c2{a[0] * w[0] - a[1] * w[1], a[0] * w[1] + a[1] * w[0]}; }

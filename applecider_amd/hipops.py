@@ -1612,7 +1612,7 @@ import os as _os
 _FFTCONV = not _os.environ.get("APPLECIDER_NO_FFTCONV")   # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
 _FFT_MATH = None      # arithmetic of the per-frequency products: None = the math mode's (fp32 or split-bf16 matrix cores)
 _FFT_FORCE = False    # tests: the transform form wherever the kernels cover the shape, whatever the cost rule says
-_FFT_MARGIN = 1.2     # the direct form must cost this many times the transform form's estimate before it is replaced
+_FFT_MARGIN = 1.0     # the direct form must cost this many times the transform form's estimate before it is replaced
 _fft_tables: dict = {}
 
 

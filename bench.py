@@ -829,8 +829,10 @@ def main():
     if "freqconv" in ks:
         d = ks["freqconv"]
         out["frequency_domain_convs"] = {
-            "what": "SpectraNet's long-tap Conv1d products (k = 251, 61 and stage 4's k = 31: forward, input gradient, "
-                    "weight gradient) computed as rfft -> per-frequency product -> irfft (ac_fft.hip, ac_gemm_batched)",
+            "what": "the SpectraNet Conv1d products that hipops.fftconv_covered() moves to the frequency domain (default "
+                    "stages at B = 512: stage 2 k = 251 and 31, stage 3 k = 61 and 15, stage 4 k = 31 and 11, stage 5 "
+                    "k = 13; forward, input gradient, weight gradient) computed as rfft -> per-frequency product -> "
+                    "irfft (ac_fft.hip, ac_gemm_batched)",
             "calls_per_step": d["launches"] // roof_steps, "ms_per_step": round(d["ms"] / roof_steps, 3),
             "direct_form_TFLOP_per_step": round(d["flops"] / roof_steps / 1e12, 3),
             "direct_form_equivalent_TFLOPs": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
