@@ -38,6 +38,26 @@ struct GemmParams {
     int64_t bs_a, bs_b, bs_c;
 };
 
+// Workgroup -> (output tile, K piece).  One K piece: XCD-aware tile order (workgroups that share an XCD, bid % 8, walk
+// contiguous tiles).  Split-K with a multiple of 8 pieces: the PIECES are dealt to the XCDs and an XCD walks the tiles
+// of one piece after another — all tiles of a piece read the same K rows of A and B, so each XCD's L2 fetches them
+// once (the 2-D grid spread the tiles of a piece over all eight L2s: the weight-gradient family moved 2.06x its
+// algorithmic bytes over the fabric, profiles/r03_pmc_hbm_traffic_bf16x3.json).
+__device__ __forceinline__ void map_workgroup(int &wg, int &piece) {
+    const int nwg = gridDim.x, pieces = gridDim.y;
+    if (pieces > 1 && (pieces & 7) == 0) {
+        const int lin = blockIdx.x + nwg * blockIdx.y;
+        const int slot = lin >> 3, round = slot / nwg;
+        piece = (lin & 7) + 8 * round;
+        wg = slot - round * nwg;
+        return;
+    }
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    piece = blockIdx.y;
+}
+
 // Batched instantiations: workgroup id -> (product z, tile), operand pointers of product z.  The XCD-aware order
 // is taken over the flattened (z, tile) range, so the tiles of one product (which share its A and B) run on one XCD.
 __device__ __forceinline__ void batch_select(const GemmParams &p, int &wg, ac_gemm_desc &d) {
@@ -458,15 +478,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware tile order: workgroups that share an XCD (bid % 8) walk contiguous tiles
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg, piece;
+    map_workgroup(wg, piece);
     ac_gemm_desc dz;
     if constexpr (BATCH) batch_select(p, wg, dz);
     const ac_gemm_desc &d = BATCH ? dz : p.d;
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = piece * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > p.nkt) kt_end = p.nkt;
     if (kt_begin >= kt_end) return;
@@ -531,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     }
 
     if (p.vec_epi == 3)
-        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile_slab(d, acc, piece, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
@@ -604,12 +623,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg, piece;
+    map_workgroup(wg, piece);
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = piece * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > p.nkt) kt_end = p.nkt;
     if (kt_begin >= kt_end) return;
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
 
     if (p.vec_epi == 3)
-        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile_slab(d, acc, piece, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
@@ -920,15 +938,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg, piece;
+    map_workgroup(wg, piece);
     ac_gemm_desc dz;
     if constexpr (BATCH) batch_select(p, wg, dz);
     const ac_gemm_desc &d = BATCH ? dz : p.d;
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = piece * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > p.nkt) kt_end = p.nkt;
     if (kt_begin >= kt_end) return;
@@ -1013,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     }
 
     if (p.vec_epi == 3)
-        store_tile_slab(d, acc, blockIdx.y, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
+        store_tile_slab(d, acc, piece, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi == 2)
         store_tile_atomic(d, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
     else if (p.vec_epi)
@@ -1059,12 +1076,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN >= 8) ? 1 : 2) void gemm_bf16
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int wg, piece;
+    map_workgroup(wg, piece);
     const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
 
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = piece * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
     if (kt_end > p.nkt) kt_end = p.nkt;
     if (kt_begin >= kt_end) return;

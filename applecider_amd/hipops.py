@@ -504,6 +504,18 @@ def conv_wgrad(dy, dy_lo, dy_batch_stride, dy_row_stride, dy_row_base, dy_col_of
     return True
 
 
+_XCD_PIECES = True    # A/B: False keeps the split factors as they come
+
+
+def _xcd_pieces(split: int) -> int:
+    """Split-K factors from 6 up become multiples of 8: the kernels then deal the K pieces to the 8 XCDs and walk the
+    tiles of one piece after another on one L2 (ac_gemm.hip map_workgroup) instead of spreading every piece's operand
+    rows over all eight."""
+    if not _XCD_PIECES or split < 6:
+        return split
+    return max(8, (split + 4) // 8 * 8)
+
+
 def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     """Split-K factor of a weight-gradient product (measured, tools/bench_split.py): long reductions
     get >= 64 K tiles per workgroup and up to 4 workgroups per CU; skinny outputs that cannot fill
@@ -519,11 +531,11 @@ def _split_for(m_out: int, n_out: int, k_red: int) -> int:
         want = 512 if nkt >= 256 else 256      # short reductions: one workgroup per CU is enough
         if tiles * split < want:
             split = max(1, min(want // tiles, nkt // 8))
-        return split
+        return _xcd_pieces(split)
     split = max(1, min(1024 // tiles, nkt // 64))
     if tiles * split < 256:
         split = max(1, min(256 // tiles, nkt // 8))
-    return split
+    return _xcd_pieces(split)
 
 
 def _tn_plan(m_out: int, n_out: int, k_red: int):

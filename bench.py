@@ -782,10 +782,17 @@ def main():
         want = {"gemm<TN>": "gemm_bf16in_kernelILb1ELi2ELi2EE", "gemm<NT>": "gemm_bf16in_kernelILb0ELi2ELi2EE",
                 "conv1d_window": "conv1d_window", "conv1d_wgrad": "conv1d_wgrad_kernel"}.get(dom_name)
         if args.math == "bf16x3" and dom_name.startswith("gemm"):
-            want = "gemm_x3_kernel"
+            # the template instance of THIS mode (A_KC, B_KC, not batched): NT = <1,1,0>, NN = <1,0,0>, TN = <0,0,0>
+            want = "gemm_x3_kernel" + {"gemm<NT>": "ILb1ELb1ELb0E", "gemm<NN>": "ILb1ELb0ELb0E",
+                                       "gemm<TN>": "ILb0ELb0ELb0E"}.get(dom_name, "")
+        if dom_name == "fft_prod":
+            want = "gemm_x3_kernel" if args.math == "bf16x3" else "gemm_f32_kernel"
+        if dom_name in ("fft_rows", "fft_taps"):
+            want = dom_name + "_"
         if args.math == "bf16x3" and dom_name == "conv1d_window":
             want = "conv1d_window_x3"
-        hits = [v for k, v in pmc.items() if want and want in k and isinstance(v, dict)]
+        hits = [v for k, v in pmc.items() if want and want in k and isinstance(v, dict)
+                and (dom_name != "fft_prod" or "ELb1EEEv" in k)]
         if hits:
             # every template instance of the family (tile shapes, MFMA forms): total bytes / total launches,
             # the same population as `achieved` (all launches of the family)

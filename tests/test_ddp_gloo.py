@@ -258,7 +258,9 @@ def test_split_k_rule_by_math_mode():
         assert a >= 1 and b >= 1
         assert a <= max(1, -(-k // 64) // 4 + 1) * 8          # at least a few K rows per workgroup
         assert a >= b                                         # the split-bf16 kernel never splits less
-    assert x3[0] == 2 * f32[0] and x3[2] == 2 * f32[2]
+    assert 1.5 * f32[0] <= x3[0] <= 2.5 * f32[0] and 1.5 * f32[2] <= x3[2] <= 2.5 * f32[2]
+    # factors from 6 up are multiples of 8: the K pieces are dealt to the 8 XCDs (ac_gemm.hip map_workgroup)
+    assert all(v < 6 or v % 8 == 0 for v in x3 + f32)
 
 
 def test_public_header_is_plain_c():
