@@ -1834,7 +1834,7 @@ class _ConvGroup1d(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, ksizes, ln_gamma, ln_beta, ln_eps, out16_only, *wb):
+    def forward(ctx, x, ksizes, ln_gamma, ln_beta, ln_eps, out16_only, pw_w, pw_b, *wb):
         x = _chk(x, "x")
         B, L, Cin = x.shape
         ws = [_chk(w, "w") for w in wb[0::2]]
@@ -1960,6 +1960,21 @@ class _ConvGroup1d(Function):
             ctx.xplanes = xplanes
         ctx.fused_ln = ln_gamma is not None
         ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
+        ctx.tail = False
+        if pw_w is not None:
+            # LayerNorm + GELU + 1x1 conv + MaxPool(4) in one kernel (ac_tail.hip): the caller checked tail_covered()
+            rows, Cpw = B * L, pw_w.shape[0]
+            z = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)      # the 1x1 weight gradient reads it
+            mean = torch.empty(rows, device=dev, dtype=torch.float32)
+            rstd = torch.empty(rows, device=dev, dtype=torch.float32)
+            pooled = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.float32)
+            pidx = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.uint8)
+            _lib.check(_lib_().ac_ln_gelu_pw_pool_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), ln_eps, _p(pw_w),
+                                                      _p(pw_b), _p(z), _p(mean), _p(rstd), _p(pooled), _p(pidx), rows,
+                                                      Ncat, Cpw, _stream()), "ac_ln_gelu_pw_pool_fwd")
+            ctx.tail, ctx.pw = True, (pw_w, pw_b)
+            ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta, z, pidx, pw_w)
+            return pooled
         if ctx.fused_ln:
             rows = B * L
             y = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
@@ -2001,10 +2016,37 @@ class _ConvGroup1d(Function):
         Lpd = L + 2 * Pmax
         dypad = dyop = None
         planes_direct, ctx_dyplanes, dy1planes = False, None, None
+        dpw_w = dpw_b = None
         if ctx.fused_ln:
             saved = ctx.saved_tensors
             xpad, ws = saved[0], list(saved[1:1 + nconv])
-            ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:]
+            ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:6 + nconv]
+            if ctx.tail:
+                # gradient of the fused tail with the kernels of the unfused one: un-pool, the 1x1 conv's weight /
+                # bias gradients from (d out, z), and d z = d out . W — the "dycat" LayerNorm's backward takes over
+                z, pidx, pw_w = saved[6 + nconv:]
+                Cpw, rows = pw_w.shape[0], B * L
+                dout = torch.empty(B, L, Cpw, device=dev, dtype=torch.float32)
+                _lib.check(_lib_().ac_maxpool4_bwd(_p(dycat), (L // 4) * Cpw, _p(pidx), _p(dout), B, L, Cpw, _stream()),
+                           "ac_maxpool4_bwd")
+                if ctx.needs_input_grad[6]:
+                    wsink = _sink(ctx.pw[0])
+                    dpw_w = wsink if wsink is not None else torch.zeros(Cpw, Ncat, device=dev, dtype=torch.float32)
+                    gemm(AC_GEMM_TN, Cpw, Ncat, rows, mat(_p(dout), Cpw), mat(_p(z), Ncat), mat(_p(dpw_w), Ncat),
+                         accumulate=2, split_k=_split_for(Cpw, Ncat, rows))
+                    if wsink is not None:
+                        dpw_w = None
+                        _grad_written(ctx.pw[0])
+                if ctx.pw[1] is not None and ctx.needs_input_grad[7]:
+                    bsink = _sink(ctx.pw[1])
+                    if bsink is not None:
+                        _lib.check(_lib_().ac_colsum(_p(dout), Cpw, _p(bsink), rows, Cpw, 1, _stream()), "ac_colsum")
+                        _grad_written(ctx.pw[1])
+                    else:
+                        dpw_b = colsum(_p(dout), Cpw, rows, Cpw, dev)
+                dz = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
+                gemm(AC_GEMM_NN, rows, Ncat, Cpw, mat(_p(dout), Cpw), mat(_p(pw_w), Ncat), mat(_p(dz), Ncat))
+                dycat, dy16in = dz, None
             gsink, bsink = _sink(ctx.params[1]), _sink(ctx.params[2])
             ln_direct = gsink is not None and bsink is not None
             dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
@@ -2211,19 +2253,37 @@ class _ConvGroup1d(Function):
                     dw = None
                     _grad_written(ctx.params[0][j])
                 grads += [dw, bias_grad(j)]
-        return (dx, None, dgam, dbet, None, None, *grads)
+        return (dx, None, dgam, dbet, None, None, dpw_w, dpw_b, *grads)
 
 
-def conv_group1d(x, ksizes, weights, biases, ln=None, out16_only=False):
+# OFF by default — measured and not adopted (profiles/r03_fused_tail_ab.txt): the one-kernel tail is correct (tests/
+# test_gpu_tail.py) but not faster.  It is bound by VALU issue (LayerNorm + GELU + the hi / lo split of every element at
+# two waves per SIMD) and by the serial latency of its statistics prologue, not by HBM: stage 1 (2 097 152 x 192 -> 64)
+# 1.42 ms against 0.72 + 0.54 + 0.13 ms for the three kernels it replaces, and on the wider stages every column tile
+# repeats the normalisation (0.55 - 0.76 ms per launch against 0.2 - 0.6 ms).  Whole step 31.2 vs 30.3 ms.
+_FUSED_TAIL = bool(_os.environ.get("APPLECIDER_FUSED_TAIL"))
+
+
+def tail_covered(B: int, L: int, Ncat: int, Cpw: int) -> bool:
+    """Whether LayerNorm + GELU + 1x1 conv + MaxPool(4) of a pooled SpectraNetBlock run as ONE forward kernel
+    (ac_ln_gelu_pw_pool_fwd, split-bf16 mode only): 128-row tiles of whole pooling groups, 32-deep K tiles."""
+    return bool(_FUSED_TAIL and x3_mode() and (B * L) % 128 == 0 and L % 4 == 0 and Ncat % 32 == 0
+                and 64 <= Ncat <= 1536 and Cpw % 32 == 0)
+
+
+def conv_group1d(x, ksizes, weights, biases, ln=None, out16_only=False, tail=None):
     """ln = (gamma, beta, eps) fuses LayerNorm + GELU over the concatenated channels.
     out16_only (bf16 math mode, with ln): the caller feeds the result straight into `linear` — the
-    fp32 output is then not written at all (its bf16 copy is), and the gradient comes back in bf16."""
+    fp32 output is then not written at all (its bf16 copy is), and the gradient comes back in bf16.
+    tail = (w [Cpw, 3 Cout], b) with ln: the 1x1 conv and MaxPool1d(4) of spectranet.py:36-40 join the same node
+    (the caller checks tail_covered); the result is the pooled [B, L / 4, Cpw] tensor."""
     args = []
     for w, b in zip(weights, biases):
         args += [w, b]
     g, bt, eps = ln if ln is not None else (None, None, 0.0)
+    pw_w, pw_b = tail if (tail is not None and ln is not None) else (None, None)
     return _ConvGroup1d.apply(x, tuple(int(k) for k in ksizes), g, bt, float(eps),
-                              bool(out16_only and ln is not None), *args)
+                              bool(out16_only and ln is not None), pw_w, pw_b, *args)
 
 
 # --------------------------------------------------------------------------- photometry branch

@@ -632,6 +632,19 @@ int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_
 int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw, float *dw,
                     ac_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Tail of a pooled SpectraNetBlock in one forward kernel (spectranet.py:31-40), split-bf16 arithmetic:
+ *     pooled[r / 4, n] = max_{j < 4} ( bias[n] + sum_k gelu(LN(ycat[4 (r/4) + j, :]))[k] * w[n, k] ),   idx = argmax j
+ * ycat [rows, K] (row stride ld), gamma / beta [K], w [N, K]; outputs: z [rows, K] = gelu(LN(ycat)) (nullable; the
+ * 1x1 conv's weight gradient reads it), mean / rstd [rows] (LayerNorm's backward), pooled [rows / 4, N], idx uint8.
+ * rows % 128 == 0 (and the pooling groups are rows 4i .. 4i + 3: L % 4 == 0), K % 32 == 0, 64 <= K <= 1536, ld == K,
+ * N % 32 == 0; 16-byte aligned.
+ * The backward pass uses ac_maxpool4_bwd, ac_gemm and ac_layernorm_bwd(_split) with these tensors.
+ * ---------------------------------------------------------------------- */
+int ac_ln_gelu_pw_pool_fwd(const float *ycat, int64_t ld, const float *gamma, const float *beta, float eps,
+                           const float *w, const float *bias, float *z, float *mean, float *rstd, float *pooled,
+                           uint8_t *idx, int64_t rows, int32_t K, int32_t N, ac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
