@@ -76,7 +76,7 @@ class FftRowsDesc(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_lo", C.c_void_p), ("spec", C.c_void_p), ("tw", C.c_void_p),
                 ("bias", C.c_void_p), ("batch_stride", C.c_int64), ("row_stride", C.c_int64),
                 ("col_off", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("logn", C.c_int32),
-                ("blocks", C.c_int32), ("block_step", C.c_int32), ("shift", C.c_int32),
+                ("radix3", C.c_int32), ("blocks", C.c_int32), ("block_step", C.c_int32), ("shift", C.c_int32),
                 ("n_lo", C.c_int32), ("n_hi", C.c_int32), ("accumulate", C.c_int32)]
 
 
@@ -178,8 +178,8 @@ SIGNATURES = {
     "ac_ln_gelu_pw_pool_fwd": [_P, _I64, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_fft_rows_fwd": [C.POINTER(FftRowsDesc), _P],
     "ac_fft_rows_inv": [C.POINTER(FftRowsDesc), _P],
-    "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
-    "ac_fft_taps_inv": [_P, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "ac_fft_taps_inv": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
 }
 ABI_VERSION = 4
 _RESTYPES = {"ac_strerror": C.c_char_p}

@@ -42,8 +42,9 @@ struct TwTable {
 // Kernels come in two register budgets: U = 4 (N >= 1024: LDS admits one or two workgroups per CU anyway) and
 // U = 1 (N <= 512: ~52 VGPRs, four workgroups per CU hide the latencies between them).
 template <int R, bool INVERSE, int SEQ, int PASS_U, int FFT_THREADS>
-__device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int arg) {
-    const int per = 1 << (logn - R), pitch = seq_pitch(logn, SEQ), total = SEQ * per;
+__device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch, int arg) {
+    // logn = log2 of the power-of-two transform; with radix3 every sequence is three of them (its thirds)
+    const int per = 1 << (logn - R), total = (radix3 ? 3 : 1) * SEQ * per, tb = third_base(1, logn);
     __syncthreads();
     for (int w0 = threadIdx.x; w0 < total; w0 += FFT_THREADS * PASS_U) {
         ac_c2 v[PASS_U][1 << R], tws[PASS_U][R];
@@ -53,7 +54,9 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
         for (int j = 0; j < PASS_U; ++j) {
             int w = w0 + j * FFT_THREADS;
             w = w < total ? w : w0;                       // (a clamped duplicate: computed, never stored)
-            seq[j] = buf + (w >> (logn - R)) * pitch;
+            const int vs = w >> (logn - R);               // virtual sequence: (sequence, third)
+            const int sq = radix3 ? vs / 3 : vs;
+            seq[j] = buf + sq * pitch + (vs - 3 * sq) * (radix3 ? tb : 0);
             const int u = w & (per - 1);
             it[j] = INVERSE ? dit_item<R>(arg, u) : dif_item<R>(logn, arg, u);
             if (INVERSE)
@@ -75,29 +78,43 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
     }
 }
 
-// natural order in -> bit-reversed order out
+// the radix-3 stage of an N = 3 * 2^logn transform over the SEQ sequences (forward: first; inverse: last)
+template <bool INVERSE, int SEQ, int FFT_THREADS>
+__device__ __forceinline__ void fft_radix3_all(ac_c2 *buf, const TwTable &tw, int logn, int pitch) {
+    const int M = 1 << logn;
+    const ac_c2 *t3 = tw.tw + M;                              // exp(-2 pi i t / N), t < 2 M, behind the M-point levels
+    auto tw3 = [&](int t) { return ac_gload<ac_c2>(t3 + t); };
+    __syncthreads();
+    for (int w = threadIdx.x; w < SEQ * M; w += FFT_THREADS) {
+        ac_c2 *seq = buf + (w >> logn) * pitch;
+        if (INVERSE)
+            dit3_item(seq, tw3, logn, w & (M - 1));
+        else
+            dif3_item(seq, tw3, logn, w & (M - 1));
+    }
+}
+
+// natural order in -> bit-reversed order out (per third when radix3)
 template <int SEQ, int U, int NT>
-__device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn) {
+__device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch) {
+    if (radix3) fft_radix3_all<false, SEQ, NT>(buf, tw, logn, pitch);
     const int r0 = first_r(logn);
-    if (r0 == 1) fft_pass_all<1, false, SEQ, U, NT>(buf, tw, logn, 0);
-    if (r0 == 2) fft_pass_all<2, false, SEQ, U, NT>(buf, tw, logn, 0);
-    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U, NT>(buf, tw, logn, s);
+    if (r0 == 1) fft_pass_all<1, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
+    if (r0 == 2) fft_pass_all<2, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
+    for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, s);
     __syncthreads();
 }
 // bit-reversed order in -> natural order out (unnormalised inverse)
 template <int SEQ, int U, int NT>
-__device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int logn) {
+__device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch) {
     const int r0 = first_r(logn);
     int lh = 0;
-    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U, NT>(buf, tw, logn, lh);
-    if (r0 == 1) fft_pass_all<1, true, SEQ, U, NT>(buf, tw, logn, lh);
-    if (r0 == 2) fft_pass_all<2, true, SEQ, U, NT>(buf, tw, logn, lh);
+    for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
+    if (r0 == 1) fft_pass_all<1, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
+    if (r0 == 2) fft_pass_all<2, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
+    if (radix3) fft_radix3_all<true, SEQ, NT>(buf, tw, logn, pitch);
     __syncthreads();
 }
-
-// position of the idx-th half-spectrum entry in the bit-reversed image: the even positions are the frequencies
-// below N / 2, position 1 is N / 2
-__device__ __forceinline__ int half_pos(int idx, int halfn) { return idx == halfn ? 1 : 2 * idx; }
 
 // workgroups that share a spectrum row (its channel groups read / write the same 128-byte lines) sit on one XCD
 __device__ __forceinline__ void map_block(int bid, int rows, int G, int &row, int &g) {
@@ -117,24 +134,27 @@ struct RowsParams {
 
 // LDS image <-> spectrum [F][rows][2C]: every lane moves one (frequency, channel pair) = 16 bytes
 template <int SEQ, int SB, int FFT_THREADS>
-__device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int64_t fstride, int logn) {
-    const int halfn = 1 << (logn - 1);
+__device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int64_t fstride, int logn, int radix3) {
+    const int halfn = ((radix3 ? 3 : 1) << logn) >> 1;
     constexpr int RS = FFT_THREADS / SEQ;
-    for (int idx0 = threadIdx.x / SEQ; idx0 <= halfn; idx0 += RS * SB) {
+    for (int e0 = threadIdx.x / SEQ; e0 <= halfn; e0 += RS * SB) {
         ac_c2 zf[SB], zn[SB];
+        int fr[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int idx = idx0 + u * RS, i = half_pos(idx <= halfn ? idx : idx0, halfn);
-            zf[u] = seq[phys(i)];
-            zn[u] = seq[phys(partner(i))];
+            const int e = e0 + u * RS;
+            int pos, ppos;
+            bool pair;
+            half_entry(e <= halfn ? e : e0, logn, radix3, pos, ppos, fr[u], pair);
+            zf[u] = seq[phys(pos)];
+            zn[u] = seq[phys(ppos)];
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int idx = idx0 + u * RS;
-            if (idx > halfn) continue;
+            if (e0 + u * RS > halfn) continue;
             ac_c2 x1, x2;
             untangle(zf[u], zn[u], x1, x2);
-            *(f32x4 *)(dst + (int64_t)brev(half_pos(idx, halfn), logn) * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
+            *(f32x4 *)(dst + (int64_t)fr[u] * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
         }
     }
 }
@@ -145,12 +165,12 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
     constexpr int RS = FFT_THREADS / SEQ;                        // rows per sweep of the workgroup
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
-    const int N = 1 << d.logn, pitch = seq_pitch(d.logn, SEQ);
+    const int N = (d.radix3 ? 3 : 1) << d.logn, pitch = seq_pitch_n(N, SEQ);
     int row, g;
     map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
     const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
     const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
-    const TwTable tw{(const ac_c2 *)d.tw, N};
+    const TwTable tw{(const ac_c2 *)d.tw, 1 << d.logn};
     ac_c2 *seq = fbuf + q * pitch;
     // sequence indices [n0, n1) take the rows l = rv + n - shift; everything else is zero
     int n0 = d.shift - rv, n1 = d.L + d.shift - rv;
@@ -181,31 +201,34 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
         for (int u = 0; u < LB; ++u)
             if (j0 + u * RS < cnt) seq[phys(n0 + j0 + u * RS)] = z[u];
     }
-    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn);
-    spectrum_store<SEQ, SB, FFT_THREADS>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn);
+    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
+    spectrum_store<SEQ, SB, FFT_THREADS>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn,
+                                         d.radix3);
 }
 
 // half spectra of the pairs (y1, y2) -> Z in the bit-reversed image; `load(f)` returns [y1.re y1.im y2.re y2.im]
 template <int SEQ, int LB, int FFT_THREADS, typename LOAD>
-__device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, LOAD load) {
-    const int halfn = 1 << (logn - 1);
+__device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, int radix3, LOAD load) {
+    const int halfn = ((radix3 ? 3 : 1) << logn) >> 1;
     constexpr int RS = FFT_THREADS / SEQ;
-    for (int idx0 = threadIdx.x / SEQ; idx0 <= halfn; idx0 += RS * LB) {
+    for (int e0 = threadIdx.x / SEQ; e0 <= halfn; e0 += RS * LB) {
         f32x4 v[LB];
+        int pos[LB], ppos[LB];
+        bool pair[LB];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-            const int idx = idx0 + u * RS;
-            v[u] = load(brev(half_pos(idx <= halfn ? idx : idx0, halfn), logn));
+            const int e = e0 + u * RS;
+            int f;
+            half_entry(e <= halfn ? e : e0, logn, radix3, pos[u], ppos[u], f, pair[u]);
+            v[u] = load(f);
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-            const int idx = idx0 + u * RS;
-            if (idx > halfn) continue;
-            const int i = half_pos(idx, halfn);
+            if (e0 + u * RS > halfn) continue;
             ac_c2 zf, zn;
             tangle(ac_c2{v[u][0], v[u][1]}, ac_c2{v[u][2], v[u][3]}, zf, zn);
-            seq[phys(i)] = zf;
-            if (i > 1) seq[phys(partner(i))] = zn;
+            seq[phys(pos[u])] = zf;
+            if (pair[u]) seq[phys(ppos[u])] = zn;
         }
     }
 }
@@ -216,17 +239,17 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kern
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
-    const int N = 1 << d.logn, pitch = seq_pitch(d.logn, SEQ);
+    const int N = (d.radix3 ? 3 : 1) << d.logn, pitch = seq_pitch_n(N, SEQ);
     int row, g;
     map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
     const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
     const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
-    const TwTable tw{(const ac_c2 *)d.tw, N};
+    const TwTable tw{(const ac_c2 *)d.tw, 1 << d.logn};
     ac_c2 *seq = fbuf + q * pitch;
     const float *src = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
     const int64_t fstride = (int64_t)d.B * d.blocks * (2 * d.C);
-    spectrum_load<SEQ, LB, FFT_THREADS>(seq, d.logn, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
-    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn);
+    spectrum_load<SEQ, LB, FFT_THREADS>(seq, d.logn, d.radix3, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
+    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
     const float inv = 1.0f / (float)N;
     // this block's output rows rv + j, j < cnt, = sequence index j + shift
     int cnt = d.L - rv;
@@ -252,7 +275,7 @@ struct TapsParams {
     const float *src;      // fwd: taps [Cout][k][Cin]; inv: M' [F][2 Cout][2 Cin]
     float *dst;            // fwd: H' [F][2 Cout][2 Cin]; inv: dw [Cout][k][Cin] (+=)
     const ac_c2 *tw;
-    int Cout, Cin, k, logn;
+    int Cout, Cin, k, logn, radix3;
 };
 
 // workgroup = (co, 2 SEQ input channels): h[m] = w[co][k - 1 - m][ci], pairs of ci transformed together
@@ -260,10 +283,10 @@ template <int SEQ, int U, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kernel(TapsParams p) {
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, halfn = N >> 1, pitch = seq_pitch(p.logn, SEQ);
+    const int N = (p.radix3 ? 3 : 1) << p.logn, halfn = N >> 1, pitch = seq_pitch_n(N, SEQ);
     const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
     const int q = threadIdx.x & (SEQ - 1);
-    const TwTable tw{p.tw, N};
+    const TwTable tw{p.tw, 1 << p.logn};
     ac_c2 *seq = fbuf + q * pitch;
     const float *w = p.src + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
     for (int m = threadIdx.x / SEQ; m < N; m += RS) {
@@ -271,15 +294,17 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kern
         const ac_c2 z = ac_gload<ac_c2>(w + (int64_t)(in ? p.k - 1 - m : 0) * p.Cin);
         seq[phys(m)] = in ? z : ac_c2{0.f, 0.f};
     }
-    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn);
+    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn, p.radix3, pitch);
     // H'[f][(co, re)][(ci, re)] = Hr, [(co, re)][(ci, im)] = -Hi, [(co, im)][(ci, re)] = Hi, [(co, im)][(ci, im)] = Hr
     const int ld = 2 * p.Cin;
     float *o = p.dst + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);
     const int64_t fstride = (int64_t)(2 * p.Cout) * ld;
-    for (int idx = threadIdx.x / SEQ; idx <= halfn; idx += RS) {
-        const int i = half_pos(idx, halfn), f = brev(i, p.logn);
+    for (int e = threadIdx.x / SEQ; e <= halfn; e += RS) {
+        int pos, ppos, f;
+        bool pair;
+        half_entry(e, p.logn, p.radix3, pos, ppos, f, pair);
         ac_c2 h1, h2;
-        untangle(seq[phys(i)], seq[phys(partner(i))], h1, h2);
+        untangle(seq[phys(pos)], seq[phys(ppos)], h1, h2);
         float *of = o + (int64_t)f * fstride;
         *(f32x4 *)of = f32x4{h1[0], -h1[1], h2[0], -h2[1]};          // row (co, re)
         *(f32x4 *)(of + ld) = f32x4{h1[1], h1[0], h2[1], h2[0]};     // row (co, im)
@@ -292,21 +317,21 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
     constexpr int LB = U == 1 ? 1 : 4;
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = 1 << p.logn, pitch = seq_pitch(p.logn, SEQ);
+    const int N = (p.radix3 ? 3 : 1) << p.logn, pitch = seq_pitch_n(N, SEQ);
     const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
     const int q = threadIdx.x & (SEQ - 1);
-    const TwTable tw{p.tw, N};
+    const TwTable tw{p.tw, 1 << p.logn};
     ac_c2 *seq = fbuf + q * pitch;
     const int ld = 2 * p.Cin;
     const float *mre = p.src + (int64_t)(2 * co) * ld + 2 * (ci0 + 2 * q);   // row (co, re); row (co, im) = + ld
     const int64_t fstride = (int64_t)(2 * p.Cout) * ld;
-    spectrum_load<SEQ, LB, FFT_THREADS>(seq, p.logn, [&](int f) {
+    spectrum_load<SEQ, LB, FFT_THREADS>(seq, p.logn, p.radix3, [&](int f) {
         // r = [M'_rr(ci) M'_ri(ci) M'_rr(ci+1) M'_ri(ci+1)], m = [M'_ir M'_ii ...]
         const float *mf = mre + (int64_t)f * fstride;
         const f32x4 r = ac_gload<f32x4>(mf), m = ac_gload<f32x4>(mf + ld);
         return f32x4{r[0] + m[1], m[0] - r[1], r[2] + m[3], m[2] - r[3]};
     });
-    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn);
+    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, p.logn, p.radix3, pitch);
     const float inv = 1.0f / (float)N;
     float *dw = p.dst + (int64_t)co * p.k * p.Cin + ci0 + 2 * q;
     for (int t = threadIdx.x / SEQ; t < p.k; t += RS) {
@@ -316,9 +341,9 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
 }
 
 template <typename K, typename P>
-int fft_launch(K kernel, int blocks, const P &p, int logn, int nseq, hipStream_t stream) {
-    const int FFT_THREADS = nseq == 4 ? 256 : 512;
-    const size_t lds = (size_t)nseq * seq_pitch(logn, nseq) * sizeof(ac_c2);
+int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream) {
+    const int FFT_THREADS = 512;
+    const size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
@@ -328,16 +353,19 @@ int fft_launch(K kernel, int blocks, const P &p, int logn, int nseq, hipStream_t
     return AC_OK;
 }
 
-bool logn_ok(int logn) { return logn >= 5 && logn <= 11; }
+// transform sizes: N = 2^logn (5 <= logn <= 11) or, radix3, N = 3 * 2^logn (3 <= logn <= 9): 24 ... 2048 points
+bool size_ok(int logn, int radix3) { return radix3 ? (radix3 == 1 && logn >= 3 && logn <= 9) : (logn >= 5 && logn <= 11); }
+int size_n(int logn, int radix3) { return (radix3 ? 3 : 1) << logn; }
 // sequences per workgroup: 32 (64 channels) for the short transforms, 8 (16 channels) otherwise.  Measured and
 // dropped for N = 2048: 4 sequences per 256-thread workgroup (74 KB of LDS, two workgroups per CU so that one loads /
 // stores while the other transforms) — the 32-byte row segments cost more than the overlap returns: stage 2's k = 251
 // convolution 2.27 ms against 1.96 ms (tools/bench_fftconv.py).
-int nseq_for(int logn, int channels) { return (logn <= 7 && channels % 64 == 0) ? 32 : 8; }
+int nseq_for(int n, int channels) { return (n <= 128 && channels % 64 == 0) ? 32 : 8; }
 
 int rows_check(const ac_fft_rows_desc &d, bool inverse) {
-    if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !logn_ok(d.logn)) return AC_EINVAL;
-    const int N = 1 << d.logn;
+    if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !size_ok(d.logn, d.radix3))
+        return AC_EINVAL;
+    const int N = size_n(d.logn, d.radix3);
     if (d.blocks < 1 || d.shift < 0 || d.shift >= N) return AC_EINVAL;
     if (d.blocks > 1 && (d.block_step < 1 || d.block_step > N || (int64_t)d.blocks * d.block_step < d.L)) return AC_EINVAL;
     if (inverse) {
@@ -361,19 +389,19 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     RowsParams p;
     p.d = *dp;
     ac_fft_rows_desc &d = p.d;
-    if (d.n_hi == 0 && d.n_lo == 0) d.n_hi = 1 << (d.logn > 0 && d.logn < 31 ? d.logn : 0);
+    if (d.n_hi == 0 && d.n_lo == 0 && size_ok(d.logn, d.radix3)) d.n_hi = size_n(d.logn, d.radix3);
     const int rc = rows_check(d, false);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
     if (ns == 32)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 512>, blocks, p, d.logn, 32, st)
-                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 512>, blocks, p, d.logn, 32, st);
-    if (d.logn >= 10)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, d.logn, 8, st)
-                         : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, d.logn, 8, st);
-    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 512>, blocks, p, d.logn, 8, st)
-                     : fft_launch(fft_rows_fwd_kernel<8, 1, false, 512>, blocks, p, d.logn, 8, st);
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 512>, blocks, p, n, 32, st)
+                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 512>, blocks, p, n, 32, st);
+    if (n >= 1024)
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, n, 8, st)
+                         : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, n, 8, st);
+    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 512>, blocks, p, n, 8, st)
+                     : fft_launch(fft_rows_fwd_kernel<8, 1, false, 512>, blocks, p, n, 8, st);
 }
 
 extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
@@ -384,36 +412,38 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     const int rc = rows_check(d, true);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int ns = nseq_for(d.logn, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
-    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 512>, blocks, p, d.logn, 32, st);
-    if (d.logn >= 10) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, d.logn, 8, st);
-    return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, d.logn, 8, st);
+    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (n >= 1024) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
+    return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }
 
-extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
-                               float *hblock, ac_stream_t stream) {
-    if (!w || !tw || !hblock || Cout <= 0 || Cin <= 0 || (Cin % 16) || k <= 0 || !logn_ok(logn) || k > (1 << logn))
+extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3,
+                               const float *tw, float *hblock, ac_stream_t stream) {
+    if (!w || !tw || !hblock || Cout <= 0 || Cin <= 0 || (Cin % 16) || k <= 0 || !size_ok(logn, radix3) ||
+        k > size_n(logn, radix3))
         return AC_EINVAL;
     if (((uintptr_t)w & 7u) || !ac_aligned16(hblock) || ((uintptr_t)tw & 7u)) return AC_EALIGN;
     TapsParams p;
-    p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
+    p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
-    const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 512>, blocks, p, logn, 32, st);
-    if (logn >= 10) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, logn, 8, st);
-    return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, logn, 8, st);
+    const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (n >= 1024) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, n, 8, st);
+    return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }
 
-extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
-                               float *dw, ac_stream_t stream) {
-    if (!m || !tw || !dw || Cout <= 0 || Cin <= 0 || (Cin % 16) || k <= 0 || !logn_ok(logn) || k > (1 << logn))
+extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3,
+                               const float *tw, float *dw, ac_stream_t stream) {
+    if (!m || !tw || !dw || Cout <= 0 || Cin <= 0 || (Cin % 16) || k <= 0 || !size_ok(logn, radix3) ||
+        k > size_n(logn, radix3))
         return AC_EINVAL;
     if (!ac_aligned16(m) || ((uintptr_t)tw & 7u) || ((uintptr_t)dw & 7u)) return AC_EALIGN;
     TapsParams p;
-    p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn;
+    p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
-    const int ns = nseq_for(logn, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 512>, blocks, p, logn, 32, st);
-    if (logn >= 10) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, logn, 8, st);
-    return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, logn, 8, st);
+    const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (n >= 1024) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
+    return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }

@@ -26,10 +26,11 @@ namespace acfft {
 AC_FFT_HD int phys(int i) { return i + (i >> 3); }
 // slots between the sequences of a workgroup: = 4 mod 32 when 8 sequences share it (lanes = 8 sequences x 4
 // consecutive elements), = 8 mod 32 for 4 sequences (x 8 elements), = 1 mod 32 for 32 sequences: distinct banks
-AC_FFT_HD int seq_pitch(int logn, int nseq = 8) {
-    const int body = (1 << logn) + (1 << (logn - 3));
+AC_FFT_HD int seq_pitch_n(int n, int nseq) {
+    const int body = n + (n >> 3);
     return ((body + 31) & ~31) + (nseq > 8 ? 1 : nseq == 4 ? 8 : 4);
 }
+AC_FFT_HD int seq_pitch(int logn, int nseq = 8) { return seq_pitch_n(1 << logn, nseq); }
 
 AC_FFT_HD ac_c2 cmul(ac_c2 a, ac_c2 w) { return ac_c2{a[0] * w[0] - a[1] * w[1], a[0] * w[1] + a[1] * w[0]}; }
 AC_FFT_HD ac_c2 conj(ac_c2 a) { return ac_c2{a[0], -a[1]}; }
@@ -152,6 +153,58 @@ AC_FFT_HD int brev(int i, int logn) {
     v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
     v = (v >> 16) | (v << 16);
     return (int)(v >> (32 - logn));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// N = 3 M, M = 2^logm >= 8 (a 'same' convolution rarely needs a power of two: stage 2's k = 251 needs 1149 points,
+// 1536 instead of 2048 is a quarter less of everything).  One radix-3 stage splits x into the thirds r = 0, 1, 2 with
+// X[3 q + r] = FFT_M( (x[j] + w^r x[j + M] + w^2r x[j + 2M]) W_N^(r j) )[q], w = exp(-2 pi i / 3); third r lives at
+// the logical positions r M .. r M + M - 1 (phys(r M + i) = phys(r M) + phys(i): the image of a third is an ordinary
+// M-point image), transformed in place by the power-of-two passes, so position r M + i holds frequency 3 brev(i) + r.
+// tw3(t) = exp(-2 pi i t / N), t < 2 M.
+// ---------------------------------------------------------------------------------------------------------------
+AC_FFT_HD int third_base(int r, int logm) { return r * ((1 << logm) + (1 << (logm - 3))); }   // = phys(r << logm)
+
+template <typename TW3>
+AC_FFT_HD void dif3_item(ac_c2 *seq, TW3 tw3, int logm, int j) {
+    const int sb = third_base(1, logm), pj = phys(j);
+    const ac_c2 a = seq[pj], b = seq[sb + pj], c = seq[2 * sb + pj];
+    const ac_c2 t1 = b + c, t2 = a - t1 * 0.5f, d = (b - c) * 0.86602540378443864676f;
+    const ac_c2 rot = {d[1], -d[0]};                       // -i d
+    seq[pj] = a + t1;
+    seq[sb + pj] = cmul(t2 + rot, tw3(j));
+    seq[2 * sb + pj] = cmul(t2 - rot, tw3(2 * j));
+}
+template <typename TW3>
+AC_FFT_HD void dit3_item(ac_c2 *seq, TW3 tw3, int logm, int j) {
+    const int sb = third_base(1, logm), pj = phys(j);
+    const ac_c2 u0 = seq[pj], u1 = cmul(seq[sb + pj], conj(tw3(j))), u2 = cmul(seq[2 * sb + pj], conj(tw3(2 * j)));
+    const ac_c2 t1 = u1 + u2, t2 = u0 - t1 * 0.5f, d = (u1 - u2) * 0.86602540378443864676f;
+    const ac_c2 rot = {-d[1], d[0]};                       // +i d
+    seq[pj] = u0 + t1;
+    seq[sb + pj] = t2 + rot;
+    seq[2 * sb + pj] = t2 - rot;
+}
+
+// The e-th entry (e <= N / 2) of the half spectrum of a real sequence: its logical position, the position of its
+// conjugate partner N - f, the frequency f itself, and whether the partner is another position (f != 0, N / 2).
+// Power of two: the even positions are the frequencies below N / 2, position 1 is N / 2.  N = 3 M: third 0 by the same
+// rule (M / 2 + 1 entries), then the even positions of third 1 (partners: the odd positions of third 2, mirrored)
+// and of third 2 (partners in third 1).
+AC_FFT_HD void half_entry(int e, int logm, int radix3, int &pos, int &ppos, int &f, bool &pair) {
+    const int M = 1 << logm, hm = M >> 1;
+    if (e <= hm) {
+        pos = e == hm ? 1 : 2 * e;
+        ppos = partner(pos);
+        pair = pos > 1;
+        f = (radix3 ? 3 : 1) * brev(pos, logm);
+        return;
+    }
+    const int e2 = e - (hm + 1), r = e2 >= hm ? 2 : 1, i = 2 * (e2 - (r - 1) * hm);
+    pos = r * M + i;
+    ppos = (3 - r) * M + (M - 1 - i);
+    pair = true;
+    f = 3 * brev(i, logm) + r;
 }
 
 // Two real sequences travel as one complex one, z = x1 + i x2.  From Z[f] and Z[N - f]:

@@ -1629,67 +1629,85 @@ _fft_tables: dict = {}
 
 
 _FFT_OVERLAP_SAVE = not _os.environ.get("APPLECIDER_FFT_NO_OVERLAP_SAVE")   # A/B: one sequence per sample only
+_FFT_RADIX3 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX3")               # A/B: power-of-two transform lengths only
 
 
-def _fft_tw(logn: int, device) -> torch.Tensor:
-    """Twiddle table of ac_fft_*: level e (transform size N >> e) = exp(-2 pi i j / (N >> e)), j < N >> (e + 1),
-    levels back to back.  Built once per size in fp64 on the host."""
-    key = (logn, str(device))
+def _fft_size(size):
+    """(logm, radix3, N) of a transform size given as log2 N (power of two) or as (logm, radix3): N = (3 if radix3 else 1) << logm."""
+    logm, r3 = (size, 0) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    return logm, r3, (3 if r3 else 1) << logm
+
+
+def _fft_tw(size, device) -> torch.Tensor:
+    """Twiddle table of ac_fft_*: M = 2^logm entries — level e (transform size M >> e) = exp(-2 pi i j / (M >> e)),
+    j < M >> (e + 1), levels back to back, one pad — then, for N = 3 M, exp(-2 pi i t / N), t < 2 M.  Built once per
+    size in fp64 on the host."""
+    logm, r3, N = _fft_size(size)
+    key = (logm, r3, str(device))
     t = _fft_tables.get(key)
     if t is None:
-        N = 1 << logn
+        M = 1 << logm
         parts = []
-        for e in range(logn):
-            n = N >> e
+        for e in range(logm):
+            n = M >> e
             ang = -2.0 * torch.pi * torch.arange(n // 2, dtype=torch.float64) / n
             parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=1))
         parts.append(torch.zeros(1, 2, dtype=torch.float64))
+        if r3:
+            ang = -2.0 * torch.pi * torch.arange(2 * M, dtype=torch.float64) / N
+            parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=1))
         t = _fft_tables[key] = torch.cat(parts).to(torch.float32).to(device)
     return t
 
 
+def _fft_sizes():
+    """Transform sizes the kernels cover, ascending: 2^m (32 ... 2048) and 3 * 2^m (24 ... 1536)."""
+    return sorted([((m, 0), 1 << m) for m in range(5, 12)] + [((m, 1), 3 << m) for m in range(3, 10)], key=lambda t: (t[1], t[0][1]))
+
+
 def fft_plan(L: int, k: int):
-    """(logn, blocks, step) of the transform form of a 'same' Conv1d with k taps on L positions.
-    blocks = 1: one sequence of N = 2^logn >= L + k // 2 points per sample (the circular wrap of the k // 2 positions
-    past either end of the linear convolution falls outside the cropped output).  blocks > 1: overlap-save — windows of
-    N points advancing by step = N - k + 1 rows; N <= 512 keeps four workgroups per CU on the transform kernels (the
-    2048-point kernel holds one), at the price of a second transform of x in the backward pass (the weight gradient
-    pairs the dy windows with x masked to each block's own rows).  None: not covered."""
+    """(logm, radix3, blocks, step) of the transform form of a 'same' Conv1d with k taps on L positions; the transform
+    length is N = 2^logm or 3 * 2^logm (a convolution needs L + k // 2 points, rarely a power of two).
+    blocks = 1: one sequence of N >= L + k // 2 points per sample (the circular wrap of the k // 2 positions past
+    either end of the linear convolution falls outside the cropped output).  blocks > 1: overlap-save — windows of
+    N <= 512 points advancing by step = N - k + 1 rows, at the price of a second transform of x in the backward pass
+    (the weight gradient pairs the dy windows with x masked to each block's own rows).  None: not covered."""
     best = None
     need = L + k // 2
-    logn1 = max(5, (need - 1).bit_length())
-    if logn1 <= 11 and k <= (1 << logn1):
-        # (measured, tools/bench_fftconv.py: stage 2's k = 251 costs the same as one 2048-point sequence, 1.91 ms, and
-        # as four 512-point windows, 1.96 ms — the window form needs a fifth transform; the sequence form is kept)
-        best = (float(1 << logn1), logn1, 1, L)
-    for logn in range(5, 10 if _FFT_OVERLAP_SAVE else 5):
-        N = 1 << logn
-        V = N - k + 1
-        if V < N // 4:
-            continue
-        blocks = -(-L // V)
-        if blocks < 2:
-            continue
-        cost = blocks * N * 1.08
-        if best is None or cost < best[0]:
-            best = (cost, logn, blocks, V)
+    for (logm, r3), N in _fft_sizes():
+        if N >= need and N >= k and (_FFT_RADIX3 or not r3):
+            # (measured, tools/bench_fftconv.py: stage 2's k = 251 costs the same as one 2048-point sequence, 1.91 ms,
+            # and as four 512-point windows, 1.96 ms — the window form needs a fifth transform)
+            best = (float(N), logm, r3, 1, L)
+            break
+    if _FFT_OVERLAP_SAVE:
+        for (logm, r3), N in _fft_sizes():
+            if N > 512 or (r3 and not _FFT_RADIX3):
+                continue
+            V = N - k + 1
+            if V < N // 4:
+                continue
+            blocks = -(-L // V)
+            if blocks < 2:
+                continue
+            cost = blocks * N * 1.08
+            if best is None or cost < best[0]:
+                best = (cost, logm, r3, blocks, V)
     return None if best is None else best[1:]
 
 
 def fft_logn(L: int, k: int):
+    """log2 of the transform length when the plan is a power of two (else None)."""
     plan = fft_plan(L, k)
-    return None if plan is None else plan[0]
+    return None if plan is None or plan[1] else plan[0]
 
 
 def fftconv_covered(B: int, L: int, Cin: int, Cout: int, k: int) -> bool:
     """Whether the three products of a 'same' Conv1d run in the frequency domain.  Shape limits of the kernels, and
     a cost rule from tools/bench_fftconv.py (profiles/r03_fftconv_kernels_*.txt): the four (five with overlap-save)
-    transforms move rows + spectrum once each at ~3.6 TB/s (2.15 TB/s on the 1024 / 2048-point kernels), the three
+    transforms move rows + spectrum once each at ~3.6 TB/s (2.15 TB/s on the >= 1024-point kernels), the three
     per-frequency products their operands at ~3 TB/s or their FLOP at ~220 TFLOP/s, whatever k is; the direct window
-    kernels sustain ~480 TFLOP/s of the 6 B L Cin Cout k FLOP (~300 on the 16-position stage).  SpectraNet's default
-    stages (default_config.toml:104-114; measured fwd + both gradients, tools/bench_fftconv.py): stage 2 k = 251
-    12.5 -> 1.96 ms and k = 31 2.0 -> 1.36 ms, stage 3 k = 61 3.2 -> 1.1 ms, stage 4 k = 31 1.7 -> 0.86 ms and k = 11
-    0.81 -> 0.70 ms, stage 5 k = 13 1.1 -> 0.77 ms; every other convolution stays direct."""
+    kernels sustain ~480 TFLOP/s of the 6 B L Cin Cout k FLOP (~300 on the 16-position stage)."""
     if not (_FFTCONV and _MATH in (_lib.MATH_F32, _lib.MATH_BF16X3) and _MODE != "f16" and Cin % 16 == 0
             and Cout % 16 == 0 and k % 2 == 1):
         return False
@@ -1698,55 +1716,61 @@ def fftconv_covered(B: int, L: int, Cin: int, Cout: int, k: int) -> bool:
         return False
     if _FFT_FORCE:
         return True
-    logn, blocks, _ = plan
-    pts, F = blocks << logn, (1 << (logn - 1)) + 1
+    logm, r3, blocks, _ = plan
+    N = (3 if r3 else 1) << logm
+    pts, F = blocks * N, N // 2 + 1
     t_bytes = (2.0 * (Cin + Cout) + (Cin if blocks > 1 else 0)) * B * 4 * (pts + L)
     p_bytes = 3.0 * (B * pts * (Cin + Cout) * 4 + F * 4 * Cin * Cout * 4)
     p_flops = 3.0 * F * 2 * B * blocks * 4 * Cin * Cout       # the split-bf16 product kernel sustains ~220 TFLOP/s
-    fft_ms = t_bytes / (2.15e9 if logn >= 10 else 3.6e9) + max(p_bytes / 3.0e9, p_flops / 220e9) + 0.05
+    fft_ms = t_bytes / (2.15e9 if N >= 1024 else 3.6e9) + max(p_bytes / 3.0e9, p_flops / 220e9) + 0.05
     direct_ms = 6.0 * B * L * Cin * Cout * k / (300e9 if L <= 16 else 480e9)
     return direct_ms >= _FFT_MARGIN * fft_ms
 
 
-def _fft_rows_desc(rows, rows_lo, elem_off, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step,
+def _fft_rows_desc(rows, rows_lo, elem_off, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, size, blocks, step,
                    shift, n_lo, n_hi, accumulate):
+    logm, r3, _ = _fft_size(size)
     d = _lib.FftRowsDesc()
     d.rows, d.rows_lo, d.spec = _p(rows, elem_off), _p(rows_lo, elem_off), _p(spec)
-    d.tw, d.bias = _p(_fft_tw(logn, spec.device)), _p(bias)
+    d.tw, d.bias = _p(_fft_tw(size, spec.device)), _p(bias)
     d.batch_stride, d.row_stride, d.col_off = batch_stride, row_stride, col_off
-    d.B, d.L, d.C, d.logn = B, L, Cn, logn
+    d.B, d.L, d.C, d.logn, d.radix3 = B, L, Cn, logm, r3
     d.blocks, d.block_step, d.shift = blocks, step, shift
     d.n_lo, d.n_hi, d.accumulate = n_lo, n_hi, int(accumulate)
     return d
 
 
-def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, logn, blocks=1, step=0,
+def fft_rows_fwd(src, src_lo, elem_off, batch_stride, row_stride, col_off, B, L, Cn, shift, size, blocks=1, step=0,
                  n_lo=0, n_hi=0) -> torch.Tensor:
     """Spectrum [N/2 + 1, B * blocks, 2 Cn] of the channels-last rows src[b, l, col_off + c] (fp32, or (hi, lo) bf16
-    planes); row l of block r sits at sequence index l - r * step + shift (inside [n_lo, n_hi) when given)."""
-    spec = torch.empty((1 << (logn - 1)) + 1, B * blocks, 2 * Cn, device=src.device, dtype=torch.float32)
-    d = _fft_rows_desc(src, src_lo, elem_off, spec, None, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step,
+    planes); row l of block r sits at sequence index l - r * step + shift (inside [n_lo, n_hi) when given).
+    size = log2 N, or (logm, radix3) for N = 3 * 2^logm."""
+    N = _fft_size(size)[2]
+    spec = torch.empty(N // 2 + 1, B * blocks, 2 * Cn, device=src.device, dtype=torch.float32)
+    d = _fft_rows_desc(src, src_lo, elem_off, spec, None, batch_stride, row_stride, col_off, B, L, Cn, size, blocks, step,
                        shift, n_lo, n_hi, 0)
     _lib.check(_lib_().ac_fft_rows_fwd(C.byref(d), _stream()), "ac_fft_rows_fwd")
     return spec
 
 
-def fft_rows_inv(spec, B, Cn, logn, dst, batch_stride, row_stride, col_off, L, shift, bias, accumulate, blocks=1, step=0):
-    d = _fft_rows_desc(dst, None, 0, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, logn, blocks, step, shift,
+def fft_rows_inv(spec, B, Cn, size, dst, batch_stride, row_stride, col_off, L, shift, bias, accumulate, blocks=1, step=0):
+    d = _fft_rows_desc(dst, None, 0, spec, bias, batch_stride, row_stride, col_off, B, L, Cn, size, blocks, step, shift,
                        0, 0, accumulate)
     _lib.check(_lib_().ac_fft_rows_inv(C.byref(d), _stream()), "ac_fft_rows_inv")
 
 
-def fft_taps_fwd(w, Cout, Cin, k, logn) -> torch.Tensor:
+def fft_taps_fwd(w, Cout, Cin, k, size) -> torch.Tensor:
     """Block spectrum [N/2 + 1, 2 Cout, 2 Cin] of the (flipped) taps w [Cout, k * Cin]."""
-    hb = torch.empty((1 << (logn - 1)) + 1, 2 * Cout, 2 * Cin, device=w.device, dtype=torch.float32)
-    _lib.check(_lib_().ac_fft_taps_fwd(_p(w), Cout, Cin, k, logn, _p(_fft_tw(logn, w.device)), _p(hb), _stream()),
+    logm, r3, N = _fft_size(size)
+    hb = torch.empty(N // 2 + 1, 2 * Cout, 2 * Cin, device=w.device, dtype=torch.float32)
+    _lib.check(_lib_().ac_fft_taps_fwd(_p(w), Cout, Cin, k, logm, r3, _p(_fft_tw(size, w.device)), _p(hb), _stream()),
                "ac_fft_taps_fwd")
     return hb
 
 
-def fft_taps_inv(mp, Cout, Cin, k, logn, dw):
-    _lib.check(_lib_().ac_fft_taps_inv(_p(mp), Cout, Cin, k, logn, _p(_fft_tw(logn, mp.device)), _p(dw), _stream()),
+def fft_taps_inv(mp, Cout, Cin, k, size, dw):
+    logm, r3, _ = _fft_size(size)
+    _lib.check(_lib_().ac_fft_taps_inv(_p(mp), Cout, Cin, k, logm, r3, _p(_fft_tw(size, mp.device)), _p(dw), _stream()),
                "ac_fft_taps_inv")
 
 
@@ -1766,8 +1790,9 @@ def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias):
     """out[b, l, col_off + co] = bias[co] + sum_{t, ci} x[b, l + t - k//2, ci] w[co, t, ci] through the frequency
     domain (spectranet.py:18-20,25).  x [B, L, Cin] fp32 contiguous, w [Cout, k * Cin] tap-major.  Returns what the
     gradient products reuse."""
-    logn, blocks, step = fft_plan(L, k)
-    F, p = (1 << (logn - 1)) + 1, k // 2
+    logm, r3, blocks, step = fft_plan(L, k)
+    logn = (logm, r3)
+    F, p = ((3 if r3 else 1) << logm) // 2 + 1, k // 2
     dev = x.device
     # one sequence per sample: x at shift 0, y read at k - 1 - p.  Overlap-save: windows from row r * step - p, y at k - 1
     xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0 if blocks == 1 else p, logn, blocks, step)
@@ -1788,7 +1813,7 @@ def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stri
     """Gradient products of fftconv_forward: dx [B, L, Cin] (nullable; stored or accumulated) and dw [Cout, k * Cin]
     (accumulated into).  dy: fp32 rows, or (dy, dy_lo) bf16 planes."""
     xs, hb, (logn, blocks, step) = saved
-    F, p = (1 << (logn - 1)) + 1, k // 2
+    F, p = _fft_size(logn)[2] // 2 + 1, k // 2
     dev, Bb = hb.device, B * blocks
     gf = fft_rows_fwd(dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cout,
                       k - 1 - p if blocks == 1 else p, logn, blocks, step)

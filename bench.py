@@ -165,8 +165,8 @@ class KernelTimer:
                 return r
             return timed
 
-        def spec_bytes(B, Cn, logn, blocks=1):
-            return 4.0 * ((1 << (logn - 1)) + 1) * B * blocks * 2 * Cn
+        def spec_bytes(B, Cn, size, blocks=1):
+            return 4.0 * (H._fft_size(size)[2] // 2 + 1) * B * blocks * 2 * Cn
 
         H.fft_rows_fwd = bracket("fft_rows", H.fft_rows_fwd,
                                  lambda src, lo, eo, bs, rs, co, B, L, Cn, sh, logn, blocks=1, *r:

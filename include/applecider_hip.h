@@ -593,8 +593,11 @@ int ac_ceil_mfma(const void *ops, float *out, int32_t shape, int32_t workgroups,
  * ac_gemm_batched: `batch` independent products of one shape in one launch; product z takes its operands
  *   bs_a / bs_b / bs_c ELEMENTS after those of product z - 1 (multiples of 4).  math = AC_MATH_F32 or
  *   AC_MATH_BF16X3, split_k = 1, 16-byte aligned operands (the matrix-core kernels; AC_EINVAL otherwise).
- * Twiddle table `tw`, provided by the caller (the library never allocates): N - 1 complex (2 floats each) entries,
- *   level e (0 <= e < logn) holds exp(-2 pi i j / (N >> e)), j < N >> (e + 1), at element offset N - (N >> e).
+ * Transform sizes: N = 2^logn, or (radix3 = 1) N = 3 * 2^logn — a 'same' convolution needs L + k/2 points, rarely a
+ *   power of two (stage 2's k = 251: 1149 -> 1536 instead of 2048).  Write M = 2^logn.
+ * Twiddle table `tw`, provided by the caller (the library never allocates): M complex (2 floats each) entries —
+ *   level e (0 <= e < logn) holds exp(-2 pi i j / (M >> e)), j < M >> (e + 1), at element offset M - (M >> e), one pad —
+ *   followed, for radix3, by exp(-2 pi i t / N), t < 2 M.
  * ac_fft_rows_fwd: every sample becomes `blocks` zero-filled length-N sequences; in block r the row
  *   rows[b, l, col_off + c] (element at b * batch_stride + l * row_stride + col_off + c; fp32, or — rows_lo non-null — a
  *   (hi, lo) bf16 plane pair of the same strides whose sum is the value), l < L, c < C, sits at sequence index
@@ -620,6 +623,7 @@ typedef struct ac_fft_rows_desc {
     const float *bias;   /* inverse only, nullable */
     int64_t batch_stride, row_stride;
     int32_t col_off, B, L, C, logn;
+    int32_t radix3;      /* 0: N = 2^logn (5 <= logn <= 11); 1: N = 3 * 2^logn (3 <= logn <= 9) */
     int32_t blocks, block_step, shift;
     int32_t n_lo, n_hi;  /* forward only */
     int32_t accumulate;  /* inverse only: rows += */
@@ -627,10 +631,10 @@ typedef struct ac_fft_rows_desc {
 int ac_gemm_batched(const ac_gemm_desc *d, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c, ac_stream_t stream);
 int ac_fft_rows_fwd(const ac_fft_rows_desc *d, ac_stream_t stream);
 int ac_fft_rows_inv(const ac_fft_rows_desc *d, ac_stream_t stream);
-int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw,
+int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3, const float *tw,
                     float *hblock, ac_stream_t stream);
-int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, const float *tw, float *dw,
-                    ac_stream_t stream);
+int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3, const float *tw,
+                    float *dw, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Tail of a pooled SpectraNetBlock in one forward kernel (spectranet.py:31-40), split-bf16 arithmetic:

@@ -29,7 +29,9 @@ def test_fft_core_against_direct_dft(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("logn")]
     assert len(lines) == 9 and all("partner ok" in l for l in lines), out.stdout
-    assert float(out.stdout.split("worst")[1]) < 1e-6
+    sizes = [l for l in out.stdout.splitlines() if l.startswith("N ")]
+    assert len(sizes) == 16 and all(l.endswith("ok") for l in sizes), out.stdout        # 7 sizes 3 * 2^m, 9 sizes 2^m
+    assert float(out.stdout.split("worst")[1].split()[0]) < 1e-6 and out.stdout.strip().endswith("fails 0")
 
 
 def test_fft_plans_of_the_default_stages():
@@ -37,17 +39,22 @@ def test_fft_plans_of_the_default_stages():
     from applecider_amd import hipops as H
     H.set_math("bf16x3")
     try:
-        assert H.fft_plan(1024, 251) == (11, 1, 1024)      # one 2048-point sequence per sample
-        assert H.fft_plan(1024, 31) == (8, 5, 226)         # overlap-save: 5 windows of 256
-        assert H.fft_plan(256, 61) == (9, 1, 256) and H.fft_plan(16, 13) == (5, 1, 16)
-        assert H.fft_plan(4096, 1021) is None              # stage 1 stays on the Toeplitz window kernels
-        for blocks_plan in (H.fft_plan(1024, 31), H.fft_plan(256, 15), H.fft_plan(64, 11)):
-            logn, blocks, step = blocks_plan
-            assert blocks > 1 and step == (1 << logn) - {5: 31, 6: 15, 3: 11}[blocks] + 1
+        assert H.fft_plan(1024, 251) == (9, 1, 1, 1024)        # one 1536-point sequence per sample (needs 1149)
+        assert H.fft_plan(1024, 31) == (7, 1, 3, 354)          # overlap-save: 3 windows of 384
+        assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(16, 13) == (3, 1, 1, 16)
+        assert H.fft_plan(4096, 1021) is None                  # stage 1 stays on the Toeplitz window kernels
+        logm, r3, blocks, step = H.fft_plan(1024, 31)
+        assert blocks > 1 and step == (3 << logm) - 31 + 1
+        H._FFT_RADIX3 = False                                  # power-of-two lengths only
+        try:
+            assert H.fft_plan(1024, 251) == (11, 0, 1, 1024) and H.fft_plan(1024, 31) == (8, 0, 5, 226)
+        finally:
+            H._FFT_RADIX3 = True
         chosen = {(L, k): H.fftconv_covered(512, L, ci, co, k) for L, ci, co, ks in
                   ((1024, 64, 128, (3, 31, 251)), (256, 128, 256, (3, 15, 61)), (64, 256, 512, (3, 11, 31)),
                    (16, 512, 1024, (3, 7, 13))) for k in ks}
-        assert [kk for kk, v in chosen.items() if v] == [(1024, 31), (1024, 251), (256, 15), (256, 61), (64, 11), (64, 31), (16, 13)]
+        assert [kk for kk, v in chosen.items() if v] == [(1024, 31), (1024, 251), (256, 15), (256, 61), (64, 11), (64, 31),
+                                                          (16, 7), (16, 13)]
         assert not H.fftconv_covered(2, 1024, 64, 128, 251)        # two samples: the taps' spectrum dominates
         assert not H.fftconv_covered(512, 1024, 1, 64, 1021)       # Cin = 1
         H.set_math("bf16")

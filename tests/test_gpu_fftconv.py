@@ -13,15 +13,16 @@ def _rel(a, b):
     return float((a.double().cpu() - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("logn", [6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("logn", [5, 6, 7, 8, 9, 10, 11, (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1)])
 @pytest.mark.parametrize("planes", [False, True])
 def test_fft_rows_roundtrip_and_spectrum(dev, logn, planes):
-    """rows -> spectrum equals torch.fft.rfft of the shifted, zero-padded rows; spectrum -> rows returns them."""
+    """rows -> spectrum equals torch.fft.rfft of the shifted, zero-padded rows; spectrum -> rows returns them.
+    Sizes: N = 2^logn (32 ... 2048) and, as (logm, 1), N = 3 * 2^logm (24 ... 1536)."""
     from applecider_amd import hipops as H
-    N = 1 << logn
+    N = H._fft_size(logn)[2]
     B, Cn, Ctot, col = 3, 32, 80, 16
     L, shift = N - 11, 5
-    g = torch.Generator().manual_seed(logn)
+    g = torch.Generator().manual_seed(N)
     x = torch.randn(B, L, Ctot, generator=g)
     xd = x.to(dev)
     if planes:
@@ -70,7 +71,18 @@ def _ref_conv(x, w, b, dy, k):
                                             (3, 100, 16, 32, 21),        # 3 windows of 64, the last one partial
                                             (2, 40, 32, 16, 49)])        # L not a power of two, N = 64
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
-def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
+@pytest.mark.parametrize("radix3", [True, False])
+def test_fftconv_products(dev, B, L, Cin, Cout, k, math, radix3):
+    """radix3 = False keeps the plans on power-of-two transform lengths (2048 points for stage 2's k = 251)."""
+    from applecider_amd import _lib, hipops as H
+    H._FFT_RADIX3 = radix3
+    try:
+        _products(dev, B, L, Cin, Cout, k, math)
+    finally:
+        H._FFT_RADIX3 = True
+
+
+def _products(dev, B, L, Cin, Cout, k, math):
     from applecider_amd import _lib, hipops as H
     assert H.fft_plan(L, k) is not None
     g = torch.Generator().manual_seed(k + L)
@@ -110,16 +122,22 @@ def test_fftconv_products(dev, B, L, Cin, Cout, k, math):
 def test_fft_plan_and_refusals(dev):
     from applecider_amd import _lib, hipops as H
     # plans of the default SpectraNet stages (default_config.toml:104-114): (logn, blocks, rows a block advances)
-    assert H.fft_plan(1024, 251) == (11, 1, 1024) and H.fft_plan(1024, 31) == (8, 5, 226)
-    assert H.fft_plan(256, 61) == (9, 1, 256) and H.fft_plan(64, 31) == (7, 1, 64) and H.fft_plan(16, 13) == (5, 1, 16)
-    assert H.fft_plan(4096, 1021) is None and H.fft_logn(900, 601) == 11
+    assert H.fft_plan(1024, 251) == (9, 1, 1, 1024) and H.fft_plan(1024, 31) == (7, 1, 3, 354)     # 1536; 3 windows of 384
+    assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(64, 31) == (5, 1, 1, 64) and H.fft_plan(16, 13) == (3, 1, 1, 16)
+    assert H.fft_plan(4096, 1021) is None
+    H._FFT_RADIX3 = False
+    try:
+        assert H.fft_plan(1024, 251) == (11, 0, 1, 1024) and H.fft_plan(1024, 31) == (8, 0, 5, 226)
+        assert H.fft_plan(256, 61) == (9, 0, 1, 256) and H.fft_logn(900, 601) == 11
+    finally:
+        H._FFT_RADIX3 = True
     lib = _lib.load()
     z = torch.zeros(8192, device=dev)
     s = H._stream()
 
     def desc(**kw):
         base = dict(rows=z, rows_lo=None, elem_off=0, spec=z, bias=None, batch_stride=64, row_stride=16, col_off=0, B=1, L=4,
-                    Cn=16, logn=6, blocks=1, step=0, shift=0, n_lo=0, n_hi=0, accumulate=0)
+                    Cn=16, size=6, blocks=1, step=0, shift=0, n_lo=0, n_hi=0, accumulate=0)
         base.update(kw)
         return H._fft_rows_desc(**base)
     import ctypes as C
@@ -128,6 +146,7 @@ def test_fft_plan_and_refusals(dev):
     assert lib.ac_fft_rows_fwd(C.byref(desc(L=60, shift=8)), s) == _lib.AC_EINVAL           # L + shift > N, one sequence
     assert lib.ac_fft_rows_fwd(C.byref(desc(L=4, blocks=2, step=1)), s) == _lib.AC_EINVAL   # blocks do not cover L
     assert lib.ac_fft_rows_inv(C.byref(desc(L=4, blocks=2, step=62, shift=8)), s) == _lib.AC_EINVAL   # step + shift > N
+    assert lib.ac_fft_rows_fwd(C.byref(desc(size=(10, 1))), s) == _lib.AC_EINVAL            # 3 * 1024 > 2048 points
     tw = H._fft_tw(6, dev)
-    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, H._p(tw), H._p(z), s) == _lib.AC_EINVAL       # k > N
-    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 5, 12, H._p(tw), H._p(z), s) == _lib.AC_EINVAL       # logn > 11
+    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, 0, H._p(tw), H._p(z), s) == _lib.AC_EINVAL    # k > N
+    assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 5, 12, 0, H._p(tw), H._p(z), s) == _lib.AC_EINVAL    # logn > 11
