@@ -22,6 +22,7 @@
 // N = 2048) or, for N <= 128, 32 of them (64 channels).  fp32 throughout: 2-5e-7 of the direct convolution.
 #include "ac_common.h"
 #include "ac_fft_core.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -43,8 +44,8 @@ struct TwTable {
 // U = 1 (N <= 512: ~52 VGPRs, four workgroups per CU hide the latencies between them).
 template <int R, bool INVERSE, int SEQ, int PASS_U, int FFT_THREADS>
 __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch, int arg) {
-    // logn = log2 of the power-of-two transform; with radix3 every sequence is three of them (its thirds)
-    const int per = 1 << (logn - R), total = (radix3 ? 3 : 1) * SEQ * per, tb = third_base(1, logn);
+    // logn = log2 of the power-of-two transform; with radix3 = a every sequence is T = 3^a of them (its pieces)
+    const int T = pow3(radix3), per = 1 << (logn - R), total = T * SEQ * per, tb = third_base(1, logn);
     __syncthreads();
     for (int w0 = threadIdx.x; w0 < total; w0 += FFT_THREADS * PASS_U) {
         ac_c2 v[PASS_U][1 << R], tws[PASS_U][R];
@@ -54,9 +55,9 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
         for (int j = 0; j < PASS_U; ++j) {
             int w = w0 + j * FFT_THREADS;
             w = w < total ? w : w0;                       // (a clamped duplicate: computed, never stored)
-            const int vs = w >> (logn - R);               // virtual sequence: (sequence, third)
-            const int sq = radix3 ? vs / 3 : vs;
-            seq[j] = buf + sq * pitch + (vs - 3 * sq) * (radix3 ? tb : 0);
+            const int vs = w >> (logn - R);               // virtual sequence: (sequence, piece)
+            const int sq = vs / T;
+            seq[j] = buf + sq * pitch + (vs - T * sq) * tb;
             const int u = w & (per - 1);
             it[j] = INVERSE ? dit_item<R>(arg, u) : dif_item<R>(logn, arg, u);
             if (INVERSE)
@@ -78,26 +79,33 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
     }
 }
 
-// the radix-3 stage of an N = 3 * 2^logn transform over the SEQ sequences (forward: first; inverse: last)
+// the radix-3 stages of an N = 3^a * 2^logn transform over the SEQ sequences (forward: first, the whole sequence
+// then its thirds; inverse: last, in the opposite order)
 template <bool INVERSE, int SEQ, int FFT_THREADS>
-__device__ __forceinline__ void fft_radix3_all(ac_c2 *buf, const TwTable &tw, int logn, int pitch) {
-    const int M = 1 << logn;
-    const ac_c2 *t3 = tw.tw + M;                              // exp(-2 pi i t / N), t < 2 M, behind the M-point levels
+__device__ __forceinline__ void fft_radix3_all(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch) {
+    const int M = 1 << logn, N = pow3(radix3) * M;
+    const ac_c2 *t3 = tw.tw + M;                              // exp(-2 pi i t / N), t < 2 N / 3, behind the M-point levels
     auto tw3 = [&](int t) { return ac_gload<ac_c2>(t3 + t); };
-    __syncthreads();
-    for (int w = threadIdx.x; w < SEQ * M; w += FFT_THREADS) {
-        ac_c2 *seq = buf + (w >> logn) * pitch;
-        if (INVERSE)
-            dit3_item(seq, tw3, logn, w & (M - 1));
-        else
-            dif3_item(seq, tw3, logn, w & (M - 1));
+    for (int k = 0; k < radix3; ++k) {
+        const int st = INVERSE ? radix3 - 1 - k : k;          // stage 0 splits the whole sequence, stage 1 its thirds
+        const int s3 = st == 0 ? N / 3 : N / 9, pieces = st == 0 ? 1 : 3, tstride = st == 0 ? 1 : 3;
+        const int per = pieces * s3;                          // butterflies per sequence in this stage (= N / 3)
+        __syncthreads();
+        for (int w = threadIdx.x; w < SEQ * per; w += FFT_THREADS) {
+            const int sq = w / per, u = w - sq * per, pc = u / s3, j = u - pc * s3;
+            ac_c2 *seq = buf + sq * pitch + phys(pc * 3 * s3);
+            if (INVERSE)
+                dit3_item(seq, tw3, s3, tstride, j);
+            else
+                dif3_item(seq, tw3, s3, tstride, j);
+        }
     }
 }
 
 // natural order in -> bit-reversed order out (per third when radix3)
 template <int SEQ, int U, int NT>
 __device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch) {
-    if (radix3) fft_radix3_all<false, SEQ, NT>(buf, tw, logn, pitch);
+    if (radix3) fft_radix3_all<false, SEQ, NT>(buf, tw, logn, radix3, pitch);
     const int r0 = first_r(logn);
     if (r0 == 1) fft_pass_all<1, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
     if (r0 == 2) fft_pass_all<2, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
@@ -112,7 +120,7 @@ __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int l
     for (; lh + 3 <= logn - r0; lh += 3) fft_pass_all<3, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
     if (r0 == 1) fft_pass_all<1, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
     if (r0 == 2) fft_pass_all<2, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
-    if (radix3) fft_radix3_all<true, SEQ, NT>(buf, tw, logn, pitch);
+    if (radix3) fft_radix3_all<true, SEQ, NT>(buf, tw, logn, radix3, pitch);
     __syncthreads();
 }
 
@@ -135,7 +143,7 @@ struct RowsParams {
 // LDS image <-> spectrum [F][rows][2C]: every lane moves one (frequency, channel pair) = 16 bytes
 template <int SEQ, int SB, int FFT_THREADS>
 __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int64_t fstride, int logn, int radix3) {
-    const int halfn = ((radix3 ? 3 : 1) << logn) >> 1;
+    const int halfn = (pow3(radix3) << logn) >> 1;
     constexpr int RS = FFT_THREADS / SEQ;
     for (int e0 = threadIdx.x / SEQ; e0 <= halfn; e0 += RS * SB) {
         ac_c2 zf[SB], zn[SB];
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
     constexpr int RS = FFT_THREADS / SEQ;                        // rows per sweep of the workgroup
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
-    const int N = (d.radix3 ? 3 : 1) << d.logn, pitch = seq_pitch_n(N, SEQ);
+    const int N = pow3(d.radix3) << d.logn, pitch = seq_pitch_n(N, SEQ);
     int row, g;
     map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
     const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kern
 // half spectra of the pairs (y1, y2) -> Z in the bit-reversed image; `load(f)` returns [y1.re y1.im y2.re y2.im]
 template <int SEQ, int LB, int FFT_THREADS, typename LOAD>
 __device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, int radix3, LOAD load) {
-    const int halfn = ((radix3 ? 3 : 1) << logn) >> 1;
+    const int halfn = (pow3(radix3) << logn) >> 1;
     constexpr int RS = FFT_THREADS / SEQ;
     for (int e0 = threadIdx.x / SEQ; e0 <= halfn; e0 += RS * LB) {
         f32x4 v[LB];
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kern
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
-    const int N = (d.radix3 ? 3 : 1) << d.logn, pitch = seq_pitch_n(N, SEQ);
+    const int N = pow3(d.radix3) << d.logn, pitch = seq_pitch_n(N, SEQ);
     int row, g;
     map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
     const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
@@ -283,7 +291,7 @@ template <int SEQ, int U, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_fwd_kernel(TapsParams p) {
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = (p.radix3 ? 3 : 1) << p.logn, halfn = N >> 1, pitch = seq_pitch_n(N, SEQ);
+    const int N = pow3(p.radix3) << p.logn, halfn = N >> 1, pitch = seq_pitch_n(N, SEQ);
     const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
     const int q = threadIdx.x & (SEQ - 1);
     const TwTable tw{p.tw, 1 << p.logn};
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
     constexpr int LB = U == 1 ? 1 : 4;
     constexpr int RS = FFT_THREADS / SEQ;
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
-    const int N = (p.radix3 ? 3 : 1) << p.logn, pitch = seq_pitch_n(N, SEQ);
+    const int N = pow3(p.radix3) << p.logn, pitch = seq_pitch_n(N, SEQ);
     const int G = p.Cin / (2 * SEQ), co = blockIdx.x / G, ci0 = (blockIdx.x % G) * 2 * SEQ;
     const int q = threadIdx.x & (SEQ - 1);
     const TwTable tw{p.tw, 1 << p.logn};
@@ -343,7 +351,17 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
 template <typename K, typename P>
 int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream) {
     const int FFT_THREADS = 512;
-    const size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
+    size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
+    static const bool exclusive = getenv("APPLECIDER_FFT_LDS_EXCLUSIVE") != nullptr;   // diagnostic: one workgroup per CU
+    if (exclusive) lds = 160 * 1024;
+    static const char *rnd = getenv("APPLECIDER_FFT_LDS_ROUND");                       // diagnostic: allocation rounding
+    if (rnd) {
+        const size_t g = (size_t)atoi(rnd);
+        if (g > 0) lds = (lds + g - 1) / g * g;
+        if (lds > 160 * 1024) lds = 160 * 1024;
+    }
+    static const char *extra = getenv("APPLECIDER_FFT_LDS_EXTRA");                     // diagnostic: slack behind the images
+    if (extra) lds = lds + (size_t)atoi(extra) > 160 * 1024 ? 160 * 1024 : lds + (size_t)atoi(extra);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
@@ -353,9 +371,13 @@ int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t st
     return AC_OK;
 }
 
-// transform sizes: N = 2^logn (5 <= logn <= 11) or, radix3, N = 3 * 2^logn (3 <= logn <= 9): 24 ... 2048 points
-bool size_ok(int logn, int radix3) { return radix3 ? (radix3 == 1 && logn >= 3 && logn <= 9) : (logn >= 5 && logn <= 11); }
-int size_n(int logn, int radix3) { return (radix3 ? 3 : 1) << logn; }
+// transform sizes: N = 2^logn (5 <= logn <= 11), N = 3 * 2^logn (radix3 = 1, 3 <= logn <= 9) or N = 9 * 2^logn
+// (radix3 = 2, 3 <= logn <= 7): 24 ... 2048 points
+bool size_ok(int logn, int radix3) {
+    if (radix3 == 0) return logn >= 5 && logn <= 11;
+    return (radix3 == 1 || radix3 == 2) && logn >= 3 && logn <= (radix3 == 1 ? 9 : 7);
+}
+int size_n(int logn, int radix3) { return pow3(radix3) << logn; }
 // sequences per workgroup: 32 (64 channels) for the short transforms, 8 (16 channels) otherwise.  Measured and
 // dropped for N = 2048: 4 sequences per 256-thread workgroup (74 KB of LDS, two workgroups per CU so that one loads /
 // stores while the other transforms) — the 32-byte row segments cost more than the overlap returns: stage 2's k = 251

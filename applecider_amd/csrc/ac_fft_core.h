@@ -156,29 +156,33 @@ AC_FFT_HD int brev(int i, int logn) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// N = 3 M, M = 2^logm >= 8 (a 'same' convolution rarely needs a power of two: stage 2's k = 251 needs 1149 points,
-// 1536 instead of 2048 is a quarter less of everything).  One radix-3 stage splits x into the thirds r = 0, 1, 2 with
-// X[3 q + r] = FFT_M( (x[j] + w^r x[j + M] + w^2r x[j + 2M]) W_N^(r j) )[q], w = exp(-2 pi i / 3); third r lives at
-// the logical positions r M .. r M + M - 1 (phys(r M + i) = phys(r M) + phys(i): the image of a third is an ordinary
-// M-point image), transformed in place by the power-of-two passes, so position r M + i holds frequency 3 brev(i) + r.
-// tw3(t) = exp(-2 pi i t / N), t < 2 M.
+// N = T M, T = 3^a (a = 1, 2), M = 2^logm >= 8 (a 'same' convolution rarely needs a power of two: stage 2's k = 251
+// needs 1149 points — 1152 = 9 * 128 instead of 2048 is 44 % less of everything).  A radix-3 stage splits a sequence
+// of length 3 S into thirds with X[3 q + r] = FFT_S( (x[j] + w^r x[j + S] + w^2r x[j + 2S]) W_3S^(r j) )[q],
+// w = exp(-2 pi i / 3); a third lives at the logical positions r S .. r S + S - 1 (phys(r S + i) = phys(r S) + phys(i):
+// its image is an ordinary S-point image), and is split again (a = 2) or transformed in place by the power-of-two
+// passes.  After both stages the M-point piece at slot 3 r1 + r2 holds the frequencies 9 q + 3 r2 + r1.
+// tw3(t) = exp(-2 pi i t / N), t < 2 N / 3.
 // ---------------------------------------------------------------------------------------------------------------
+AC_FFT_HD int pow3(int a) { return a == 2 ? 9 : (a == 1 ? 3 : 1); }
 AC_FFT_HD int third_base(int r, int logm) { return r * ((1 << logm) + (1 << (logm - 3))); }   // = phys(r << logm)
 
+// one radix-3 butterfly of a stage whose thirds are `s3` elements long (s3 % 8 == 0), at the image `seq` of that
+// 3 * s3 point sequence; twiddles W_(3 s3)^j = tw3(j * tstride)
 template <typename TW3>
-AC_FFT_HD void dif3_item(ac_c2 *seq, TW3 tw3, int logm, int j) {
-    const int sb = third_base(1, logm), pj = phys(j);
+AC_FFT_HD void dif3_item(ac_c2 *seq, TW3 tw3, int s3, int tstride, int j) {
+    const int sb = phys(s3), pj = phys(j);
     const ac_c2 a = seq[pj], b = seq[sb + pj], c = seq[2 * sb + pj];
     const ac_c2 t1 = b + c, t2 = a - t1 * 0.5f, d = (b - c) * 0.86602540378443864676f;
     const ac_c2 rot = {d[1], -d[0]};                       // -i d
     seq[pj] = a + t1;
-    seq[sb + pj] = cmul(t2 + rot, tw3(j));
-    seq[2 * sb + pj] = cmul(t2 - rot, tw3(2 * j));
+    seq[sb + pj] = cmul(t2 + rot, tw3(j * tstride));
+    seq[2 * sb + pj] = cmul(t2 - rot, tw3(2 * j * tstride));
 }
 template <typename TW3>
-AC_FFT_HD void dit3_item(ac_c2 *seq, TW3 tw3, int logm, int j) {
-    const int sb = third_base(1, logm), pj = phys(j);
-    const ac_c2 u0 = seq[pj], u1 = cmul(seq[sb + pj], conj(tw3(j))), u2 = cmul(seq[2 * sb + pj], conj(tw3(2 * j)));
+AC_FFT_HD void dit3_item(ac_c2 *seq, TW3 tw3, int s3, int tstride, int j) {
+    const int sb = phys(s3), pj = phys(j);
+    const ac_c2 u0 = seq[pj], u1 = cmul(seq[sb + pj], conj(tw3(j * tstride))), u2 = cmul(seq[2 * sb + pj], conj(tw3(2 * j * tstride)));
     const ac_c2 t1 = u1 + u2, t2 = u0 - t1 * 0.5f, d = (u1 - u2) * 0.86602540378443864676f;
     const ac_c2 rot = {-d[1], d[0]};                       // +i d
     seq[pj] = u0 + t1;
@@ -188,23 +192,24 @@ AC_FFT_HD void dit3_item(ac_c2 *seq, TW3 tw3, int logm, int j) {
 
 // The e-th entry (e <= N / 2) of the half spectrum of a real sequence: its logical position, the position of its
 // conjugate partner N - f, the frequency f itself, and whether the partner is another position (f != 0, N / 2).
-// Power of two: the even positions are the frequencies below N / 2, position 1 is N / 2.  N = 3 M: third 0 by the same
-// rule (M / 2 + 1 entries), then the even positions of third 1 (partners: the odd positions of third 2, mirrored)
-// and of third 2 (partners in third 1).
+// Power of two: the even positions are the frequencies below N / 2, position 1 is N / 2.  N = T M: the residue 0 piece
+// by the same rule (M / 2 + 1 entries), then for every residue s = 1 .. T - 1 the even positions of its piece; the
+// partner of (s, i) is (T - s, M - 1 - i).  Residue s sits at slot s (T = 3) or 3 (s % 3) + s / 3 (T = 9).
 AC_FFT_HD void half_entry(int e, int logm, int radix3, int &pos, int &ppos, int &f, bool &pair) {
-    const int M = 1 << logm, hm = M >> 1;
+    const int M = 1 << logm, hm = M >> 1, T = pow3(radix3);
     if (e <= hm) {
         pos = e == hm ? 1 : 2 * e;
         ppos = partner(pos);
         pair = pos > 1;
-        f = (radix3 ? 3 : 1) * brev(pos, logm);
+        f = T * brev(pos, logm);
         return;
     }
-    const int e2 = e - (hm + 1), r = e2 >= hm ? 2 : 1, i = 2 * (e2 - (r - 1) * hm);
-    pos = r * M + i;
-    ppos = (3 - r) * M + (M - 1 - i);
+    const int e2 = e - (hm + 1), s = 1 + e2 / hm, i = 2 * (e2 - (s - 1) * hm), sp = T - s;
+    const int slot = T == 9 ? 3 * (s % 3) + s / 3 : s, pslot = T == 9 ? 3 * (sp % 3) + sp / 3 : sp;
+    pos = slot * M + i;
+    ppos = pslot * M + (M - 1 - i);
     pair = true;
-    f = 3 * brev(i, logm) + r;
+    f = T * brev(i, logm) + s;
 }
 
 // Two real sequences travel as one complex one, z = x1 + i x2.  From Z[f] and Z[N - f]:

@@ -1630,12 +1630,21 @@ _fft_tables: dict = {}
 
 _FFT_OVERLAP_SAVE = not _os.environ.get("APPLECIDER_FFT_NO_OVERLAP_SAVE")   # A/B: one sequence per sample only
 _FFT_RADIX3 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX3")               # A/B: power-of-two transform lengths only
+_FFT_SHARE = not _os.environ.get("APPLECIDER_FFT_NO_SHARE")                 # A/B: no sharing of spectra inside a bank
+# Transform lengths 9 * 2^m (1152 points for stage 2's k = 251, 288 for stage 3, 72 for stage 4's k = 11) are built,
+# tested and ~0.4 ms per step faster eagerly — and OFF by default: inside a hipGraph whose other branches run beside
+# the spectra encoder, these launches (like the four-window form of k = 251 before them) came out wrong by up to 1 % of
+# the spectra embedding, replay after replay differently, while the same launches are bit-exact eagerly (one or three
+# streams), in a one-branch graph, and in the three-branch graph as soon as their LDS request is rounded up to 64 KB
+# (APPLECIDER_FFT_LDS_ROUND=65536) or to the whole CU.  LDS sizes granted are the ones requested (tools/lds_probe.hip);
+# no explanation yet.  tests/test_gpu_graphstep.py holds the bit-identity test that catches it.
+_FFT_RADIX9 = bool(_os.environ.get("APPLECIDER_FFT_RADIX9"))
 
 
 def _fft_size(size):
     """(logm, radix3, N) of a transform size given as log2 N (power of two) or as (logm, radix3): N = (3 if radix3 else 1) << logm."""
     logm, r3 = (size, 0) if isinstance(size, int) else (int(size[0]), int(size[1]))
-    return logm, r3, (3 if r3 else 1) << logm
+    return logm, r3, (1, 3, 9)[r3] << logm
 
 
 def _fft_tw(size, device) -> torch.Tensor:
@@ -1654,15 +1663,16 @@ def _fft_tw(size, device) -> torch.Tensor:
             parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=1))
         parts.append(torch.zeros(1, 2, dtype=torch.float64))
         if r3:
-            ang = -2.0 * torch.pi * torch.arange(2 * M, dtype=torch.float64) / N
+            ang = -2.0 * torch.pi * torch.arange(2 * N // 3, dtype=torch.float64) / N
             parts.append(torch.stack([torch.cos(ang), torch.sin(ang)], dim=1))
         t = _fft_tables[key] = torch.cat(parts).to(torch.float32).to(device)
     return t
 
 
 def _fft_sizes():
-    """Transform sizes the kernels cover, ascending: 2^m (32 ... 2048) and 3 * 2^m (24 ... 1536)."""
-    return sorted([((m, 0), 1 << m) for m in range(5, 12)] + [((m, 1), 3 << m) for m in range(3, 10)], key=lambda t: (t[1], t[0][1]))
+    """Transform sizes the kernels cover, ascending: 2^m (32 ... 2048), 3 * 2^m (24 ... 1536), 9 * 2^m (72 ... 1152)."""
+    return sorted([((m, 0), 1 << m) for m in range(5, 12)] + [((m, 1), 3 << m) for m in range(3, 10)] +
+                  [((m, 2), 9 << m) for m in range(3, 8)], key=lambda t: (t[1], t[0][1]))
 
 
 def fft_plan(L: int, k: int):
@@ -1675,17 +1685,19 @@ def fft_plan(L: int, k: int):
     best = None
     need = L + k // 2
     for (logm, r3), N in _fft_sizes():
-        if N >= need and N >= k and (_FFT_RADIX3 or not r3):
+        if N >= need and N >= k and (_FFT_RADIX3 or not r3) and (_FFT_RADIX9 or r3 < 2):
             # (measured, tools/bench_fftconv.py: stage 2's k = 251 costs the same as one 2048-point sequence, 1.91 ms,
             # and as four 512-point windows, 1.96 ms — the window form needs a fifth transform)
-            best = (float(N), logm, r3, 1, L)
+            # (the >= 1024-point kernels hold one workgroup per CU and move 2.1 TB/s against 3.6 for the shorter ones:
+            # stage 2's k = 31 costs 1.78 ms as one 1152-point sequence, 1.29 ms as three 384-point windows)
+            best = (N * (1.4 if N >= 1024 else 1.0), logm, r3, 1, L)
             break
     if _FFT_OVERLAP_SAVE:
         for (logm, r3), N in _fft_sizes():
-            if N > 512 or (r3 and not _FFT_RADIX3):
+            if N > 512 or (r3 and not _FFT_RADIX3) or (r3 == 2 and not _FFT_RADIX9):
                 continue
             V = N - k + 1
-            if V < N // 4:
+            if V < 0.6 * N:       # windows that overlap by more than 40 % transform most points twice
                 continue
             blocks = -(-L // V)
             if blocks < 2:
@@ -1717,7 +1729,7 @@ def fftconv_covered(B: int, L: int, Cin: int, Cout: int, k: int) -> bool:
     if _FFT_FORCE:
         return True
     logm, r3, blocks, _ = plan
-    N = (3 if r3 else 1) << logm
+    N = _fft_size((logm, r3))[2]
     pts, F = blocks * N, N // 2 + 1
     t_bytes = (2.0 * (Cin + Cout) + (Cin if blocks > 1 else 0)) * B * 4 * (pts + L)
     p_bytes = 3.0 * (B * pts * (Cin + Cout) * 4 + F * 4 * Cin * Cout * 4)
@@ -1774,28 +1786,29 @@ def fft_taps_inv(mp, Cout, Cin, k, size, dw):
                "ac_fft_taps_inv")
 
 
-def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c, math=None):
+def gemm_batched(mode, M, N, K, a: Mat, b: Mat, c: Mat, batch, bs_a, bs_b, bs_c, math=None, accumulate=0):
     d = GemmDesc()
     if math is None:
         math = _FFT_MATH if _FFT_MATH is not None else (_lib.MATH_BF16X3 if _MATH == _lib.MATH_BF16X3 else _lib.MATH_F32)
     d.mode, d.math = mode, math
     d.M, d.N, d.K = int(M), int(N), int(K)
-    d.split_k, d.alpha = 1, 1.0
+    d.split_k, d.alpha, d.accumulate = 1, 1.0, int(accumulate)
     d.a, d.b, d.c = a, b, c
     _lib.check(_lib_().ac_gemm_batched(C.byref(d), int(batch), int(bs_a), int(bs_b), int(bs_c), _stream()),
                "ac_gemm_batched")
 
 
-def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias):
+def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias, xf=None):
     """out[b, l, col_off + co] = bias[co] + sum_{t, ci} x[b, l + t - k//2, ci] w[co, t, ci] through the frequency
     domain (spectranet.py:18-20,25).  x [B, L, Cin] fp32 contiguous, w [Cout, k * Cin] tap-major.  Returns what the
     gradient products reuse."""
     logm, r3, blocks, step = fft_plan(L, k)
     logn = (logm, r3)
-    F, p = ((3 if r3 else 1) << logm) // 2 + 1, k // 2
+    F, p = _fft_size(logn)[2] // 2 + 1, k // 2
     dev = x.device
     # one sequence per sample: x at shift 0, y read at k - 1 - p.  Overlap-save: windows from row r * step - p, y at k - 1
-    xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0 if blocks == 1 else p, logn, blocks, step)
+    if xf is None or blocks > 1:      # (xf: the spectrum another convolution of the bank made with the same plan)
+        xf = fft_rows_fwd(x, None, 0, L * Cin, Cin, 0, B, L, Cin, 0 if blocks == 1 else p, logn, blocks, step)
     hb = fft_taps_fwd(w, Cout, Cin, k, logn)
     Bb = B * blocks
     yf = torch.empty(F, Bb, 2 * Cout, device=dev, dtype=torch.float32)
@@ -1809,7 +1822,7 @@ def fftconv_forward(x, w, B, L, Cin, Cout, k, out, ld_out, col_off, bias):
 
 
 def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cin, Cout, k,
-                     dx, dx_accumulate, dw):
+                     dx, dx_accumulate, dw, dx_group=None):
     """Gradient products of fftconv_forward: dx [B, L, Cin] (nullable; stored or accumulated) and dw [Cout, k * Cin]
     (accumulated into).  dy: fp32 rows, or (dy, dy_lo) bf16 planes."""
     xs, hb, (logn, blocks, step) = saved
@@ -1817,7 +1830,16 @@ def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stri
     dev, Bb = hb.device, B * blocks
     gf = fft_rows_fwd(dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stride, dy_col_off, B, L, Cout,
                       k - 1 - p if blocks == 1 else p, logn, blocks, step)
-    if dx is not None:
+    if dx is not None and dx_group is not None and blocks == 1:
+        # convolutions of one bank with the same plan: their input-gradient spectra add up in ONE buffer and are
+        # transformed back once (the caller's fftconv_finish_dx)
+        first = dx_group.get("dxf") is None
+        if first:
+            dx_group["dxf"], dx_group["size"] = torch.empty(F, Bb, 2 * Cin, device=dev, dtype=torch.float32), logn
+        gemm_batched(AC_GEMM_NN, Bb, 2 * Cin, 2 * Cout, mat(_p(gf), 2 * Cout), mat(_p(hb), 2 * Cin),
+                     mat(_p(dx_group["dxf"]), 2 * Cin), F, Bb * 2 * Cout, 4 * Cout * Cin, Bb * 2 * Cin,
+                     accumulate=0 if first else 1)
+    elif dx is not None:
         dxf = torch.empty(F, Bb, 2 * Cin, device=dev, dtype=torch.float32)
         gemm_batched(AC_GEMM_NN, Bb, 2 * Cin, 2 * Cout, mat(_p(gf), 2 * Cout), mat(_p(hb), 2 * Cin), mat(_p(dxf), 2 * Cin),
                      F, Bb * 2 * Cout, 4 * Cout * Cin, Bb * 2 * Cin)
@@ -1828,6 +1850,11 @@ def fftconv_backward(saved, dy, dy_lo, dy_elem_off, dy_batch_stride, dy_row_stri
         gemm_batched(AC_GEMM_TN, 2 * Cout, 2 * Cin, Bb, mat(_p(gf), 2 * Cout), mat(_p(xf), 2 * Cin), mat(_p(mp), 2 * Cin),
                      F, Bb * 2 * Cout, Bb * 2 * Cin, 4 * Cout * Cin)
         fft_taps_inv(mp, Cout, Cin, k, logn, dw)
+
+
+def fftconv_finish_dx(dx_group, dx, dx_accumulate, B, L, Cin):
+    """The one inverse transform of a bank's summed input-gradient spectra (see fftconv_backward)."""
+    fft_rows_inv(dx_group["dxf"], B, Cin, dx_group["size"], dx, L * Cin, Cin, 0, L, 0, None, dx_accumulate)
 
 
 def _pad_rows(x, B, L, Cn, pad_lo, Lp):
@@ -1953,11 +1980,17 @@ class _ConvGroup1d(Function):
             planes_only = bool(xplanes is not None and _CONVWIN_X3_FUSED and _WGRAD_WIN and L % 128 == 0
                                and Cin % 64 == 0 and Cout % 128 == 0)
             xpad = None if planes_only else (_pad_rows16 if b16 else _pad_rows)(x, B, L, Cin, Pmax, Lp)
+            xf_shared = {}
             for j, k in enumerate(ksizes):
                 off = Pmax - k // 2
                 if not b16 and fftconv_covered(B, L, Cin, Cout, k):
-                    # long taps: the three products of this convolution run in the frequency domain (ac_fft.hip)
-                    ctx.fft[j] = fftconv_forward(x, ws[j], B, L, Cin, Cout, k, ycat, Ncat, j * Cout, bs[j])
+                    # long taps: the three products of this convolution run in the frequency domain (ac_fft.hip);
+                    # convolutions of the bank with the same transform plan share the spectrum of x
+                    plan = fft_plan(L, k)
+                    shared = xf_shared.get(plan) if (_FFT_SHARE and plan[2] == 1) else None
+                    ctx.fft[j] = fftconv_forward(x, ws[j], B, L, Cin, Cout, k, ycat, Ncat, j * Cout, bs[j], xf=shared)
+                    if plan[2] == 1:
+                        xf_shared[plan] = ctx.fft[j][0]
                     continue
                 if xplanes is not None and conv_window_x3(
                         xplanes, Lp * Cin, Cin, 0, off, B, L, Cin, k, split16_w(ws[j]), k * Cin, Cin, False, Cout,
@@ -2199,6 +2232,11 @@ class _ConvGroup1d(Function):
             if need_dx:
                 dx = torch.empty(B, L, Cin, device=dev, dtype=torch.float32)
             dyplanes = ctx_dyplanes if planes_direct else (_pad_rows_split(dycat, B, L, Ncat, Pmax, Lpd) if x3win else None)
+            # convolutions in the frequency domain that share a plan (one sequence per sample) sum their input-gradient
+            # spectra and transform back once, after the loop; `dx_started` = something already wrote dx
+            plans = [ctx.fft[j][2] for j in ctx.fft]
+            groups = {pl: {} for pl in set(plans) if _FFT_SHARE and pl[1] == 1 and plans.count(pl) > 1}
+            dx_started = False
             for j, k in enumerate(ksizes):
                 p = k // 2
                 off = Pmax - p
@@ -2209,8 +2247,11 @@ class _ConvGroup1d(Function):
                         src = (dycat, None, 0, L * Ncat)
                     else:                      # the zero-padded (hi, lo) planes LayerNorm's backward wrote
                         src = (dyplanes[0], dyplanes[1], Pmax * Ncat, Lpd * Ncat)
+                    grp = groups.get(ctx.fft[j][2])
                     fftconv_backward(ctx.fft[j], src[0], src[1], src[2], src[3], Ncat, j * Cout, B, L, Cin, Cout, k,
-                                     dx if ctx.needs_input_grad[0] else None, j > 0, dw)
+                                     dx if ctx.needs_input_grad[0] else None, dx_started, dw, dx_group=grp)
+                    if grp is None and ctx.needs_input_grad[0]:
+                        dx_started = True
                     if wsink is not None:
                         dw = None
                         _grad_written(ctx.params[0][j])
@@ -2218,8 +2259,8 @@ class _ConvGroup1d(Function):
                     continue
                 if ctx.needs_input_grad[0] and dyplanes is not None and conv_window_x3(
                         dyplanes, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, split16_wT(ctx.params[0][j]),
-                        Cout, Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):
-                    pass
+                        Cout, Cin * Cout, True, Cin, _p(dx), Cin, None, dx_started):
+                    dx_started = True
                 elif ctx.needs_input_grad[0] and planes_direct:
                     raise RuntimeError("split-bf16 conv bank: the plane-fed window kernel refused a shape that "
                                        "_x3_bank_covered() admits")
@@ -2233,8 +2274,9 @@ class _ConvGroup1d(Function):
                         # inner index (t, co) through an offset table
                         wT = cast16_wT(ctx.params[0][j])  # [k*Cin, Cout]
                         if conv_window(dypad, Lpd * Ncat, Ncat, j * Cout, off, B, L, Cout, k, wT, Cout,
-                                       Cin * Cout, True, Cin, _p(dx), Cin, None, j > 0):
+                                       Cin * Cout, True, Cin, _p(dx), Cin, None, dx_started):
                             wT = None
+                            dx_started = True
                     if b16 and wT is not None:
                         goff_b = _table(("cg_dxw", Cin, Cout, k),
                                         lambda k=k: [t * Cin * Cout + cb * 32 for t in range(k)
@@ -2242,14 +2284,16 @@ class _ConvGroup1d(Function):
                         gemm(AC_GEMM_NT, B * L, Cin, k * Cout,
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(wT), Cout, goff=goff_b), mat(_p(dx), Cin),
-                             accumulate=0 if j == 0 else 1, math=mth)
+                             accumulate=1 if dx_started else 0, math=mth)
+                        dx_started = True
                     elif not b16:
                         if dypad is None:
                             dypad = _pad_rows(dycat, B, L, Ncat, Pmax, Lpd)
                         gemm(AC_GEMM_NN, B * L, Cin, k * Cout,
                              mat(_p(dypad), r1=L, r2=L, s1=Lpd * Ncat, s3=Ncat, goff=goff),
                              mat(_p(ws[j]), r1=Cout, r2=Cout, s1=Cin, s3=k * Cin),
-                             mat(_p(dx), Cin), accumulate=0 if j == 0 else 1)
+                             mat(_p(dx), Cin), accumulate=1 if dx_started else 0)
+                        dx_started = True
                 wsink = _sink(ctx.params[0][j])
                 dw = wsink if wsink is not None else torch.zeros(Cout, k * Cin, device=dev,
                                                                   dtype=torch.float32)
@@ -2278,6 +2322,11 @@ class _ConvGroup1d(Function):
                     dw = None
                     _grad_written(ctx.params[0][j])
                 grads += [dw, bias_grad(j)]
+        if Cin != 1 and ctx.needs_input_grad[0]:
+            for grp in groups.values():
+                if grp.get("dxf") is not None:
+                    fftconv_finish_dx(grp, dx, dx_started, B, L, Cin)
+                    dx_started = True
         return (dx, None, dgam, dbet, None, None, dpw_w, dpw_b, *grads)
 
 

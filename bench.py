@@ -180,13 +180,13 @@ class KernelTimer:
                                  lambda mp, Cout, Cin, k, logn, dw: (0.0, 8.0 * Cout * Cin * k + spec_bytes(2 * Cout, Cin, logn)))
         # whole convolutions (outer brackets over the launches above): the FLOP of the direct form they replace
         H.fftconv_forward = bracket("freqconv", H.fftconv_forward,
-                                    lambda x, w, B, L, Cin, Cout, k, *r: (2.0 * B * L * Cin * Cout * k, 0.0))
+                                    lambda x, w, B, L, Cin, Cout, k, *r, **kw: (2.0 * B * L * Cin * Cout * k, 0.0))
         H.fftconv_backward = bracket("freqconv", H.fftconv_backward,
-                                     lambda saved, dy, lo, eo, bs, rs, co, B, L, Cin, Cout, k, dx, acc, dw:
+                                     lambda saved, dy, lo, eo, bs, rs, co, B, L, Cin, Cout, k, dx, acc, dw, **kw:
                                      (2.0 * B * L * Cin * Cout * k * ((dx is not None) + (dw is not None)), 0.0))
         H.gemm_batched = bracket("fft_prod", H.gemm_batched,
                                  lambda mode, M, N, K, a, b, c, batch, *r, **kw:
-                                 (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N)))
+                                 (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + (2 if kw.get("accumulate") else 1) * M * N)))
 
     def wrap_dwconv(self, H):
         lib = H._lib_()

@@ -593,11 +593,11 @@ int ac_ceil_mfma(const void *ops, float *out, int32_t shape, int32_t workgroups,
  * ac_gemm_batched: `batch` independent products of one shape in one launch; product z takes its operands
  *   bs_a / bs_b / bs_c ELEMENTS after those of product z - 1 (multiples of 4).  math = AC_MATH_F32 or
  *   AC_MATH_BF16X3, split_k = 1, 16-byte aligned operands (the matrix-core kernels; AC_EINVAL otherwise).
- * Transform sizes: N = 2^logn, or (radix3 = 1) N = 3 * 2^logn — a 'same' convolution needs L + k/2 points, rarely a
- *   power of two (stage 2's k = 251: 1149 -> 1536 instead of 2048).  Write M = 2^logn.
+ * Transform sizes: N = 2^logn, N = 3 * 2^logn (radix3 = 1) or N = 9 * 2^logn (radix3 = 2) — a 'same' convolution needs
+ *   L + k/2 points, rarely a power of two (stage 2's k = 251: 1149 -> 1152 instead of 2048).  Write M = 2^logn.
  * Twiddle table `tw`, provided by the caller (the library never allocates): M complex (2 floats each) entries —
  *   level e (0 <= e < logn) holds exp(-2 pi i j / (M >> e)), j < M >> (e + 1), at element offset M - (M >> e), one pad —
- *   followed, for radix3, by exp(-2 pi i t / N), t < 2 M.
+ *   followed, for radix3 > 0, by exp(-2 pi i t / N), t < 2 N / 3.
  * ac_fft_rows_fwd: every sample becomes `blocks` zero-filled length-N sequences; in block r the row
  *   rows[b, l, col_off + c] (element at b * batch_stride + l * row_stride + col_off + c; fp32, or — rows_lo non-null — a
  *   (hi, lo) bf16 plane pair of the same strides whose sum is the value), l < L, c < C, sits at sequence index
@@ -623,7 +623,8 @@ typedef struct ac_fft_rows_desc {
     const float *bias;   /* inverse only, nullable */
     int64_t batch_stride, row_stride;
     int32_t col_off, B, L, C, logn;
-    int32_t radix3;      /* 0: N = 2^logn (5 <= logn <= 11); 1: N = 3 * 2^logn (3 <= logn <= 9) */
+    int32_t radix3;      /* radix-3 stages: 0: N = 2^logn (5 <= logn <= 11); 1: N = 3 * 2^logn (3 <= logn <= 9);
+                            2: N = 9 * 2^logn (3 <= logn <= 7) */
     int32_t blocks, block_step, shift;
     int32_t n_lo, n_hi;  /* forward only */
     int32_t accumulate;  /* inverse only: rows += */

@@ -43,10 +43,10 @@ static void inverse(ac_c2 *seq, const std::vector<ac_c2> &tw, int logn) {
 }
 
 static int run_size(int logm, int radix3) {
-    const int M = 1 << logm, N = (radix3 ? 3 : 1) * M;
+    const int M = 1 << logm, T = pow3(radix3), N = T * M;
     const auto tw = table(logm);
-    std::vector<ac_c2> tw3(2 * M);
-    for (int t = 0; t < 2 * M; ++t) {
+    std::vector<ac_c2> tw3(2 * N / 3 + 1);
+    for (int t = 0; t < (int)tw3.size(); ++t) {
         const double a = -2.0 * M_PI * t / N;
         tw3[t] = ac_c2{(float)cos(a), (float)sin(a)};
     }
@@ -60,12 +60,13 @@ static int run_size(int logm, int radix3) {
     const int pitch = seq_pitch_n(N, 8);
     std::vector<ac_c2> seq(pitch, ac_c2{0.f, 0.f});
     for (int n = 0; n < N; ++n) seq[phys(n)] = ac_c2{(float)x1[n], (float)x2[n]};
-    if (radix3) {
-        for (int j = 0; j < M; ++j) dif3_item(seq.data(), t3, logm, j);
-        for (int r = 0; r < 3; ++r) forward(seq.data() + third_base(r, logm), tw, logm);
-    } else {
-        forward(seq.data(), tw, logm);
+    // radix-3 stages (what fft_radix3_all does), then the power-of-two passes on every M-point piece
+    for (int st = 0; st < radix3; ++st) {
+        const int s3 = N / (st == 0 ? 3 : 9), pieces = st == 0 ? 1 : 3, tstride = st == 0 ? 1 : 3;
+        for (int pc = 0; pc < pieces; ++pc)
+            for (int j = 0; j < s3; ++j) dif3_item(seq.data() + phys(pc * 3 * s3), t3, s3, tstride, j);
     }
+    for (int r = 0; r < T; ++r) forward(seq.data() + third_base(r, logm), tw, logm);
     std::vector<double> ar(N), ai(N), br(N), bi(N);
     for (int f = 0; f < N; ++f) {
         double s1r = 0, s1i = 0, s2r = 0, s2i = 0;
@@ -100,22 +101,23 @@ static int run_size(int logm, int radix3) {
         inv[phys(pos)] = zf;
         if (pair) inv[phys(ppos)] = zn;
     }
-    if (radix3) {
-        for (int r = 0; r < 3; ++r) inverse(inv.data() + third_base(r, logm), tw, logm);
-        for (int j = 0; j < M; ++j) dit3_item(inv.data(), t3, logm, j);
-    } else {
-        inverse(inv.data(), tw, logm);
+    for (int r = 0; r < T; ++r) inverse(inv.data() + third_base(r, logm), tw, logm);
+    for (int st = radix3 - 1; st >= 0; --st) {
+        const int s3 = N / (st == 0 ? 3 : 9), pieces = st == 0 ? 1 : 3, tstride = st == 0 ? 1 : 3;
+        for (int pc = 0; pc < pieces; ++pc)
+            for (int j = 0; j < s3; ++j) dit3_item(inv.data() + phys(pc * 3 * s3), t3, s3, tstride, j);
     }
     for (int n = 0; n < N; ++n)
         e_inv = fmax(e_inv, fmax(fabs(inv[phys(n)][0] / N - x1[n]), fabs(inv[phys(n)][1] / N - x2[n])));
     if (!(e_inv == e_inv)) bad = 1;    // a position of the image was never written
-    printf("N %4d (%s)  half spectrum %.2e  roundtrip %.2e  %s\n", N, radix3 ? "3 x 2^m" : "2^m", e_unt, e_inv, bad ? "BAD" : "ok");
+    printf("N %4d (%s)  half spectrum %.2e  roundtrip %.2e  %s\n", N, radix3 == 2 ? "9 x 2^m" : radix3 ? "3 x 2^m" : "2^m", e_unt, e_inv, bad ? "BAD" : "ok");
     return (bad || e_unt > 2e-6 || e_inv > 2e-6) ? 1 : 0;
 }
 
 int main() {
     double worst = 0.0;
     int fails = 0;
+    for (int logm = 3; logm <= 7; ++logm) fails += run_size(logm, 2);      // N = 72 ... 1152
     for (int logm = 3; logm <= 9; ++logm) fails += run_size(logm, 1);      // N = 24 ... 1536
     for (int logm = 3; logm <= 11; ++logm) fails += run_size(logm, 0);
     for (int logn = 3; logn <= 11; ++logn) {

@@ -30,7 +30,7 @@ def test_fft_core_against_direct_dft(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.startswith("logn")]
     assert len(lines) == 9 and all("partner ok" in l for l in lines), out.stdout
     sizes = [l for l in out.stdout.splitlines() if l.startswith("N ")]
-    assert len(sizes) == 16 and all(l.endswith("ok") for l in sizes), out.stdout        # 7 sizes 3 * 2^m, 9 sizes 2^m
+    assert len(sizes) == 21 and all(l.endswith("ok") for l in sizes), out.stdout        # 5 sizes 9 * 2^m, 7 of 3 * 2^m, 9 of 2^m
     assert float(out.stdout.split("worst")[1].split()[0]) < 1e-6 and out.stdout.strip().endswith("fails 0")
 
 
@@ -41,10 +41,15 @@ def test_fft_plans_of_the_default_stages():
     try:
         assert H.fft_plan(1024, 251) == (9, 1, 1, 1024)        # one 1536-point sequence per sample (needs 1149)
         assert H.fft_plan(1024, 31) == (7, 1, 3, 354)          # overlap-save: 3 windows of 384
-        assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(16, 13) == (3, 1, 1, 16)
+        assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(16, 13) == (3, 1, 1, 16)       # 384, 24 points
+        H._FFT_RADIX9 = True                                   # lengths 9 * 2^m: built, off by default (hipops._FFT_RADIX9)
+        try:
+            assert H.fft_plan(1024, 251) == (7, 2, 1, 1024) and H.fft_plan(256, 61) == (5, 2, 1, 256)
+        finally:
+            H._FFT_RADIX9 = False
         assert H.fft_plan(4096, 1021) is None                  # stage 1 stays on the Toeplitz window kernels
-        logm, r3, blocks, step = H.fft_plan(1024, 31)
-        assert blocks > 1 and step == (3 << logm) - 31 + 1
+        logm, r3, blocks, step = H.fft_plan(2048, 31)          # overlap-save where one sequence would not fit
+        assert blocks > 1 and step == H._fft_size((logm, r3))[2] - 31 + 1
         H._FFT_RADIX3 = False                                  # power-of-two lengths only
         try:
             assert H.fft_plan(1024, 251) == (11, 0, 1, 1024) and H.fft_plan(1024, 31) == (8, 0, 5, 226)

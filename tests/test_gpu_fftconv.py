@@ -13,11 +13,12 @@ def _rel(a, b):
     return float((a.double().cpu() - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("logn", [5, 6, 7, 8, 9, 10, 11, (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1)])
+@pytest.mark.parametrize("logn", [5, 6, 7, 8, 9, 10, 11, (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1),
+                                  (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)])
 @pytest.mark.parametrize("planes", [False, True])
 def test_fft_rows_roundtrip_and_spectrum(dev, logn, planes):
     """rows -> spectrum equals torch.fft.rfft of the shifted, zero-padded rows; spectrum -> rows returns them.
-    Sizes: N = 2^logn (32 ... 2048) and, as (logm, 1), N = 3 * 2^logm (24 ... 1536)."""
+    Sizes: N = 2^logn (32 ... 2048) and, as (logm, a), N = 3^a * 2^logm (24 ... 1536, 72 ... 1152)."""
     from applecider_amd import hipops as H
     N = H._fft_size(logn)[2]
     B, Cn, Ctot, col = 3, 32, 80, 16
@@ -71,15 +72,16 @@ def _ref_conv(x, w, b, dy, k):
                                             (3, 100, 16, 32, 21),        # 3 windows of 64, the last one partial
                                             (2, 40, 32, 16, 49)])        # L not a power of two, N = 64
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
-@pytest.mark.parametrize("radix3", [True, False])
+@pytest.mark.parametrize("radix3", [True, False, 9])
 def test_fftconv_products(dev, B, L, Cin, Cout, k, math, radix3):
-    """radix3 = False keeps the plans on power-of-two transform lengths (2048 points for stage 2's k = 251)."""
+    """radix3 = False keeps the plans on power-of-two transform lengths (2048 points for stage 2's k = 251); 9 also
+    admits the lengths 9 * 2^m (1152 points for it), which the default plans leave out (hipops._FFT_RADIX9)."""
     from applecider_amd import _lib, hipops as H
-    H._FFT_RADIX3 = radix3
+    H._FFT_RADIX3, H._FFT_RADIX9 = bool(radix3), radix3 == 9
     try:
         _products(dev, B, L, Cin, Cout, k, math)
     finally:
-        H._FFT_RADIX3 = True
+        H._FFT_RADIX3, H._FFT_RADIX9 = True, False
 
 
 def _products(dev, B, L, Cin, Cout, k, math):
@@ -124,6 +126,11 @@ def test_fft_plan_and_refusals(dev):
     # plans of the default SpectraNet stages (default_config.toml:104-114): (logn, blocks, rows a block advances)
     assert H.fft_plan(1024, 251) == (9, 1, 1, 1024) and H.fft_plan(1024, 31) == (7, 1, 3, 354)     # 1536; 3 windows of 384
     assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(64, 31) == (5, 1, 1, 64) and H.fft_plan(16, 13) == (3, 1, 1, 16)
+    H._FFT_RADIX9 = True
+    try:
+        assert H.fft_plan(1024, 251) == (7, 2, 1, 1024) and H.fft_plan(256, 61) == (5, 2, 1, 256)   # 1152 = 9 * 128, 288
+    finally:
+        H._FFT_RADIX9 = False
     assert H.fft_plan(4096, 1021) is None
     H._FFT_RADIX3 = False
     try:
@@ -147,6 +154,7 @@ def test_fft_plan_and_refusals(dev):
     assert lib.ac_fft_rows_fwd(C.byref(desc(L=4, blocks=2, step=1)), s) == _lib.AC_EINVAL   # blocks do not cover L
     assert lib.ac_fft_rows_inv(C.byref(desc(L=4, blocks=2, step=62, shift=8)), s) == _lib.AC_EINVAL   # step + shift > N
     assert lib.ac_fft_rows_fwd(C.byref(desc(size=(10, 1))), s) == _lib.AC_EINVAL            # 3 * 1024 > 2048 points
+    assert lib.ac_fft_rows_fwd(C.byref(desc(size=(8, 2))), s) == _lib.AC_EINVAL             # 9 * 256 > 2048 points
     tw = H._fft_tw(6, dev)
     assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 65, 6, 0, H._p(tw), H._p(z), s) == _lib.AC_EINVAL    # k > N
     assert lib.ac_fft_taps_fwd(H._p(z), 2, 16, 5, 12, 0, H._p(tw), H._p(z), s) == _lib.AC_EINVAL    # logn > 11
