@@ -349,20 +349,17 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
 }
 
 template <typename K, typename P>
-int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream) {
-    const int FFT_THREADS = 512;
+int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream, int FFT_THREADS = 512) {
+    // EVERY transform workgroup asks for the whole LDS of a CU (160 KB), so that it shares its CU with nothing.
+    // Measured (tools/dbg_coresidency*.py): beside workgroups of OTHER kernels (the attention kernels,
+    // the photometry forward, the image backward; never the gather-GEMM, LayerNorm or its own kind) a transform
+    // workgroup returns a few wrong values — the imaginary half of some partner elements read after the last pass —
+    // in up to 100 % of the launches, eagerly and in graphs, while LDS allocations do not overlap (tools/lds_probe.hip)
+    // and the kernel is bit-exact alone, at any batch size.  With the CU to itself: 0 of 100.  Cause unexplained.
     size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
-    static const bool exclusive = getenv("APPLECIDER_FFT_LDS_EXCLUSIVE") != nullptr;   // diagnostic: one workgroup per CU
-    if (exclusive) lds = 160 * 1024;
-    static const char *rnd = getenv("APPLECIDER_FFT_LDS_ROUND");                       // diagnostic: allocation rounding
-    if (rnd) {
-        const size_t g = (size_t)atoi(rnd);
-        if (g > 0) lds = (lds + g - 1) / g * g;
-        if (lds > 160 * 1024) lds = 160 * 1024;
-    }
-    static const char *extra = getenv("APPLECIDER_FFT_LDS_EXTRA");                     // diagnostic: slack behind the images
-    if (extra) lds = lds + (size_t)atoi(extra) > 160 * 1024 ? 160 * 1024 : lds + (size_t)atoi(extra);
-    if (lds > 64 * 1024) {
+    static const bool shared_cu = getenv("APPLECIDER_FFT_SHARED_CU") != nullptr;      // diagnostic: the exact request
+    if (!shared_cu) lds = 160 * 1024;
+    {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
     }
@@ -382,7 +379,9 @@ int size_n(int logn, int radix3) { return pow3(radix3) << logn; }
 // dropped for N = 2048: 4 sequences per 256-thread workgroup (74 KB of LDS, two workgroups per CU so that one loads /
 // stores while the other transforms) — the 32-byte row segments cost more than the overlap returns: stage 2's k = 251
 // convolution 2.27 ms against 1.96 ms (tools/bench_fftconv.py).
-int nseq_for(int n, int channels) { return (n <= 128 && channels % 64 == 0) ? 32 : 8; }
+// With the CU to itself a workgroup should be as large as it can: 32 sequences x 1024 threads for N <= 512 (148 KB of
+// images at N = 512) when the channel count allows, else 8 sequences x 512 threads.
+int nseq_for(int n, int channels) { return (n <= 512 && channels % 64 == 0) ? 32 : 8; }
 
 int rows_check(const ac_fft_rows_desc &d, bool inverse) {
     if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !size_ok(d.logn, d.radix3))
@@ -417,8 +416,8 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
     if (ns == 32)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 512>, blocks, p, n, 32, st)
-                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 512>, blocks, p, n, 32, st);
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 1024>, blocks, p, n, 32, st, 1024)
+                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024)
         return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, n, 8, st)
                          : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, n, 8, st);
@@ -435,7 +434,7 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
-    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }
@@ -450,7 +449,7 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }
@@ -465,7 +464,7 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 512>, blocks, p, n, 32, st);
+    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }

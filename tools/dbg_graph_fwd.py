@@ -11,7 +11,7 @@ orig = H.fftconv_covered
 if os.environ.get("ONLYK"):
     H.fftconv_covered = lambda B, L, Cin, Cout, k: k == int(os.environ["ONLYK"]) and orig(B, L, Cin, Cout, k)
 print("plan k=251", H.fft_plan(1024, 251), "only k", os.environ.get("ONLYK"))
-m, batches = T._fused(dev)
+m, batches = T._fused(dev, B=int(os.environ.get('BATCH', '8')))
 m.eval()
 bt = batches[0]
 
