@@ -381,7 +381,11 @@ int size_n(int logn, int radix3) { return pow3(radix3) << logn; }
 // convolution 2.27 ms against 1.96 ms (tools/bench_fftconv.py).
 // With the CU to itself a workgroup should be as large as it can: 32 sequences x 1024 threads for N <= 512 (148 KB of
 // images at N = 512) when the channel count allows, else 8 sequences x 512 threads.
-int nseq_for(int n, int channels) { return (n <= 512 && channels % 64 == 0) ? 32 : 8; }
+// The shortest transforms (N <= 96: stages 4 and 5) take 128 sequences = 256 channels per workgroup.
+int nseq_for(int n, int channels) {
+    if (n <= 96 && channels % 256 == 0) return 128;
+    return (n <= 512 && channels % 64 == 0) ? 32 : 8;
+}
 
 int rows_check(const ac_fft_rows_desc &d, bool inverse) {
     if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !size_ok(d.logn, d.radix3))
@@ -415,6 +419,9 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    if (ns == 128)
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<128, 1, true, 1024>, blocks, p, n, 128, st, 1024)
+                         : fft_launch(fft_rows_fwd_kernel<128, 1, false, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32)
         return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 1024>, blocks, p, n, 32, st, 1024)
                          : fft_launch(fft_rows_fwd_kernel<32, 1, false, 1024>, blocks, p, n, 32, st, 1024);
@@ -434,6 +441,7 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    if (ns == 128) return fft_launch(fft_rows_inv_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
@@ -449,6 +457,7 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 128) return fft_launch(fft_taps_fwd_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, n, 8, st);
@@ -464,6 +473,7 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
+    if (ns == 128) return fft_launch(fft_taps_inv_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
     if (n >= 1024) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
