@@ -1631,14 +1631,10 @@ _fft_tables: dict = {}
 _FFT_OVERLAP_SAVE = not _os.environ.get("APPLECIDER_FFT_NO_OVERLAP_SAVE")   # A/B: one sequence per sample only
 _FFT_RADIX3 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX3")               # A/B: power-of-two transform lengths only
 _FFT_SHARE = not _os.environ.get("APPLECIDER_FFT_NO_SHARE")                 # A/B: no sharing of spectra inside a bank
-# Transform lengths 9 * 2^m (1152 points for stage 2's k = 251, 288 for stage 3, 72 for stage 4's k = 11) are built,
-# tested and ~0.4 ms per step faster eagerly — and OFF by default: inside a hipGraph whose other branches run beside
-# the spectra encoder, these launches (like the four-window form of k = 251 before them) came out wrong by up to 1 % of
-# the spectra embedding, replay after replay differently, while the same launches are bit-exact eagerly (one or three
-# streams), in a one-branch graph, and in the three-branch graph as soon as their LDS request is rounded up to 64 KB
-# (APPLECIDER_FFT_LDS_ROUND=65536) or to the whole CU.  LDS sizes granted are the ones requested (tools/lds_probe.hip);
-# no explanation yet.  tests/test_gpu_graphstep.py holds the bit-identity test that catches it.
-_FFT_RADIX9 = bool(_os.environ.get("APPLECIDER_FFT_RADIX9"))
+# Transform lengths 9 * 2^m (1152 points for stage 2's k = 251, 288 for stage 3, 72 for stage 4's k = 11).  They were the
+# first plans on which the co-residency problem of the transform kernels showed (profiles/r03_fft_coresidency_
+# investigation.txt); with every transform workgroup alone on its CU they are as exact as the others.
+_FFT_RADIX9 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX9")
 
 
 def _fft_size(size):
@@ -1703,7 +1699,7 @@ def fft_plan(L: int, k: int):
             if blocks < 2:
                 continue
             cost = blocks * N * 1.08
-            if best is None or cost < best[0]:
+            if best is None or cost <= best[0]:      # (ties: the longer windows, fewer of them)
                 best = (cost, logm, r3, blocks, V)
     return None if best is None else best[1:]
 

@@ -39,14 +39,13 @@ def test_fft_plans_of_the_default_stages():
     from applecider_amd import hipops as H
     H.set_math("bf16x3")
     try:
-        assert H.fft_plan(1024, 251) == (9, 1, 1, 1024)        # one 1536-point sequence per sample (needs 1149)
-        assert H.fft_plan(1024, 31) == (7, 1, 3, 354)          # overlap-save: 3 windows of 384
-        assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(16, 13) == (3, 1, 1, 16)       # 384, 24 points
-        H._FFT_RADIX9 = True                                   # lengths 9 * 2^m: built, off by default (hipops._FFT_RADIX9)
+        assert H.fft_plan(1024, 251) == (7, 2, 1, 1024)        # one 1152-point sequence per sample (needs 1149)
+        assert H.fft_plan(256, 61) == (5, 2, 1, 256) and H.fft_plan(16, 13) == (3, 1, 1, 16)       # 288, 24 points
+        H._FFT_RADIX9 = False                                  # lengths 2^m and 3 * 2^m only
         try:
-            assert H.fft_plan(1024, 251) == (7, 2, 1, 1024) and H.fft_plan(256, 61) == (5, 2, 1, 256)
+            assert H.fft_plan(1024, 251) == (9, 1, 1, 1024) and H.fft_plan(1024, 31) == (7, 1, 3, 354)
         finally:
-            H._FFT_RADIX9 = False
+            H._FFT_RADIX9 = True
         assert H.fft_plan(4096, 1021) is None                  # stage 1 stays on the Toeplitz window kernels
         logm, r3, blocks, step = H.fft_plan(2048, 31)          # overlap-save where one sequence would not fit
         assert blocks > 1 and step == H._fft_size((logm, r3))[2] - 31 + 1

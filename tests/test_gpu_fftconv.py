@@ -75,13 +75,13 @@ def _ref_conv(x, w, b, dy, k):
 @pytest.mark.parametrize("radix3", [True, False, 9])
 def test_fftconv_products(dev, B, L, Cin, Cout, k, math, radix3):
     """radix3 = False keeps the plans on power-of-two transform lengths (2048 points for stage 2's k = 251); 9 also
-    admits the lengths 9 * 2^m (1152 points for it), which the default plans leave out (hipops._FFT_RADIX9)."""
+    admits the lengths 9 * 2^m (1152 points for it; the default), True stops at 3 * 2^m (1536)."""
     from applecider_amd import _lib, hipops as H
     H._FFT_RADIX3, H._FFT_RADIX9 = bool(radix3), radix3 == 9
     try:
         _products(dev, B, L, Cin, Cout, k, math)
     finally:
-        H._FFT_RADIX3, H._FFT_RADIX9 = True, False
+        H._FFT_RADIX3, H._FFT_RADIX9 = True, True
 
 
 def _products(dev, B, L, Cin, Cout, k, math):
@@ -124,13 +124,14 @@ def _products(dev, B, L, Cin, Cout, k, math):
 def test_fft_plan_and_refusals(dev):
     from applecider_amd import _lib, hipops as H
     # plans of the default SpectraNet stages (default_config.toml:104-114): (logn, blocks, rows a block advances)
-    assert H.fft_plan(1024, 251) == (9, 1, 1, 1024) and H.fft_plan(1024, 31) == (7, 1, 3, 354)     # 1536; 3 windows of 384
-    assert H.fft_plan(256, 61) == (7, 1, 1, 256) and H.fft_plan(64, 31) == (5, 1, 1, 64) and H.fft_plan(16, 13) == (3, 1, 1, 16)
-    H._FFT_RADIX9 = True
+    assert H.fft_plan(1024, 251) == (7, 2, 1, 1024) and H.fft_plan(256, 61) == (5, 2, 1, 256)      # 1152 = 9 * 128, 288 points
+    assert H.fft_plan(64, 31) == (5, 1, 1, 64) and H.fft_plan(16, 13) == (3, 1, 1, 16)            # 96, 24 points
+    H._FFT_RADIX9 = False
     try:
-        assert H.fft_plan(1024, 251) == (7, 2, 1, 1024) and H.fft_plan(256, 61) == (5, 2, 1, 256)   # 1152 = 9 * 128, 288
+        assert H.fft_plan(1024, 251) == (9, 1, 1, 1024) and H.fft_plan(1024, 31) == (7, 1, 3, 354)  # 1536; 3 windows of 384
+        assert H.fft_plan(256, 61) == (7, 1, 1, 256)
     finally:
-        H._FFT_RADIX9 = False
+        H._FFT_RADIX9 = True
     assert H.fft_plan(4096, 1021) is None
     H._FFT_RADIX3 = False
     try:
