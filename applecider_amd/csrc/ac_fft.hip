@@ -167,51 +167,95 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
     }
 }
 
+// A rows workgroup owns its CU (fft_launch), so nothing else hides its memory latency: it walks SEVERAL tiles
+// (tile = SEQ sequences of one spectrum row; tiles t, t + gridDim.x, ... — gridDim.x is a multiple of 8, so all of them
+// sit on the workgroup's XCD) and the global loads of the next tile are issued, into registers, before the passes of
+// the current one; the spectrum / row stores of a tile drain while the next one is transformed.
+struct RawPair {
+    unsigned a, b;     // two fp32 (bit patterns) or the packed (hi, hi) / (lo, lo) bf16 pairs of a channel pair
+};
+
 template <int SEQ, int U, bool PLANES, int FFT_THREADS>
-__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_fwd_kernel(RowsParams p) {
-    constexpr int LB = U == 1 ? 2 : 8, SB = U == 1 ? 2 : 4;     // global loads / LDS reads in flight per thread
+__global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2) void fft_rows_fwd_kernel(RowsParams p) {
+    constexpr int SB = U == 1 ? 2 : 4;                           // LDS reads in flight per thread in the spectrum store
     constexpr int RS = FFT_THREADS / SEQ;                        // rows per sweep of the workgroup
+    constexpr int EPT = U == 1 ? 16 : 32;                        // rows of one sequence per thread: N / RS at most
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
     const int N = pow3(d.radix3) << d.logn, pitch = seq_pitch_n(N, SEQ);
-    int row, g;
-    map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
-    const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
-    const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
+    const int rows = d.B * d.blocks, G = d.C / (2 * SEQ), total = rows * G, W = gridDim.x;
+    const int q = threadIdx.x & (SEQ - 1), r0 = threadIdx.x / SEQ;
     const TwTable tw{(const ac_c2 *)d.tw, 1 << d.logn};
     ac_c2 *seq = fbuf + q * pitch;
-    // sequence indices [n0, n1) take the rows l = rv + n - shift; everything else is zero
-    int n0 = d.shift - rv, n1 = d.L + d.shift - rv;
-    n0 = n0 > d.n_lo ? n0 : d.n_lo;
-    n1 = n1 < d.n_hi ? n1 : d.n_hi;
-    n1 = n1 < N ? n1 : N;
-    n1 = n1 > n0 ? n1 : n0;
-    for (int n = threadIdx.x / SEQ; n < N; n += RS)
-        if (n < n0 || n >= n1) seq[phys(n)] = ac_c2{0.f, 0.f};
-    const int cnt = n1 - n0;
-    const int64_t off = (int64_t)b * d.batch_stride + (int64_t)(rv + n0 - d.shift) * d.row_stride + d.col_off + c0 + 2 * q;
-    for (int j0 = threadIdx.x / SEQ; j0 < cnt; j0 += RS * LB) {
-        ac_c2 z[LB];
+    const int64_t fstride = (int64_t)rows * (2 * d.C);
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+
+    // sequence indices [n0, n1) of tile `t` take the rows l = rv + n - shift; everything else is zero
+    int row, c0, n0, n1;
+    int64_t off;
+    auto locate = [&](int t) __attribute__((always_inline)) {
+        int g;
+        map_block(t, rows, G, row, g);
+        const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
+        c0 = g * 2 * SEQ;
+        n0 = d.shift - rv;
+        n1 = d.L + d.shift - rv;
+        n0 = n0 > d.n_lo ? n0 : d.n_lo;
+        n1 = n1 < d.n_hi ? n1 : d.n_hi;
+        n1 = n1 < N ? n1 : N;
+        n1 = n1 > n0 ? n1 : n0;
+        off = (int64_t)b * d.batch_stride + (int64_t)(rv + n0 - d.shift) * d.row_stride + d.col_off + c0 + 2 * q;
+    };
+    RawPair z[EPT];
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int cnt = n1 - n0;
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int j = j0 + u * RS;
-            const int64_t a = off + (int64_t)(j < cnt ? j : j0) * d.row_stride;
+        for (int u = 0; u < EPT; ++u) {
+            if (u * RS >= cnt) break;
+            const int j = r0 + u * RS;
+            const int64_t a = off + (int64_t)(j < cnt ? j : 0) * d.row_stride;     // clamped; masked when written to LDS
             if (PLANES) {
-                const unsigned h = ac_gload<unsigned>((const unsigned short *)d.rows + a);
-                const unsigned lo = ac_gload<unsigned>((const unsigned short *)d.rows_lo + a);
-                z[u] = ac_c2{ac_h2f((unsigned short)(h & 0xFFFFu)) + ac_h2f((unsigned short)(lo & 0xFFFFu)),
-                             ac_h2f((unsigned short)(h >> 16)) + ac_h2f((unsigned short)(lo >> 16))};
+                z[u].a = ac_gload<unsigned>((const unsigned short *)d.rows + a);
+                z[u].b = ac_gload<unsigned>((const unsigned short *)d.rows_lo + a);
             } else {
-                z[u] = ac_gload<ac_c2>((const float *)d.rows + a);
+                const ac_c2 v = ac_gload<ac_c2>((const float *)d.rows + a);
+                z[u].a = __float_as_uint(v[0]);
+                z[u].b = __float_as_uint(v[1]);
             }
         }
+    };
+    locate(tile);
+    issue();
+    for (;;) {
+        const int cnt = n1 - n0;
+        for (int n = r0; n < N; n += RS)
+            if (n < n0 || n >= n1) seq[phys(n)] = ac_c2{0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < LB; ++u)
-            if (j0 + u * RS < cnt) seq[phys(n0 + j0 + u * RS)] = z[u];
+        for (int u = 0; u < EPT; ++u) {
+            if (u * RS >= cnt) break;
+            const int j = r0 + u * RS;
+            if (j >= cnt) continue;
+            ac_c2 v;
+            if (PLANES)
+                v = ac_c2{ac_h2f((unsigned short)(z[u].a & 0xFFFFu)) + ac_h2f((unsigned short)(z[u].b & 0xFFFFu)),
+                          ac_h2f((unsigned short)(z[u].a >> 16)) + ac_h2f((unsigned short)(z[u].b >> 16))};
+            else
+                v = ac_c2{__uint_as_float(z[u].a), __uint_as_float(z[u].b)};
+            seq[phys(n0 + j)] = v;
+        }
+        float *dst = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
+        tile += W;
+        const bool more = tile < total;
+        if (more) {
+            locate(tile);
+            issue();
+        }
+        fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
+        spectrum_store<SEQ, SB, FFT_THREADS>(seq, dst, fstride, d.logn, d.radix3);
+        if (!more) break;
+        __syncthreads();                                         // the image is rewritten
     }
-    fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
-    spectrum_store<SEQ, SB, FFT_THREADS>(seq, d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q), (int64_t)d.B * d.blocks * (2 * d.C), d.logn,
-                                         d.radix3);
 }
 
 // half spectra of the pairs (y1, y2) -> Z in the bit-reversed image; `load(f)` returns [y1.re y1.im y2.re y2.im]
@@ -242,40 +286,89 @@ __device__ __forceinline__ void spectrum_load(ac_c2 *seq, int logn, int radix3, 
 }
 
 template <int SEQ, int U, int FFT_THREADS>
-__global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_rows_inv_kernel(RowsParams p) {
+__global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2) void fft_rows_inv_kernel(RowsParams p) {
     constexpr int LB = U == 1 ? 2 : 8;
     constexpr int RS = FFT_THREADS / SEQ;
+    constexpr int EPS = U == 1 ? 9 : 17;                          // half-spectrum entries per thread: (N / 2 + 1) / RS at most
     extern __shared__ __attribute__((aligned(16))) ac_c2 fbuf[];
     const ac_fft_rows_desc &d = p.d;
-    const int N = pow3(d.radix3) << d.logn, pitch = seq_pitch_n(N, SEQ);
-    int row, g;
-    map_block(blockIdx.x, d.B * d.blocks, d.C / (2 * SEQ), row, g);
-    const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step;
-    const int q = threadIdx.x & (SEQ - 1), c0 = g * 2 * SEQ;
+    const int N = pow3(d.radix3) << d.logn, halfn = N >> 1, pitch = seq_pitch_n(N, SEQ);
+    const int rows = d.B * d.blocks, G = d.C / (2 * SEQ), total = rows * G, W = gridDim.x;
+    const int q = threadIdx.x & (SEQ - 1), r0 = threadIdx.x / SEQ;
     const TwTable tw{(const ac_c2 *)d.tw, 1 << d.logn};
     ac_c2 *seq = fbuf + q * pitch;
-    const float *src = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
-    const int64_t fstride = (int64_t)d.B * d.blocks * (2 * d.C);
-    spectrum_load<SEQ, LB, FFT_THREADS>(seq, d.logn, d.radix3, [&](int f) { return ac_gload<f32x4>(src + (int64_t)f * fstride); });
-    fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
+    const int64_t fstride = (int64_t)rows * (2 * d.C);
     const float inv = 1.0f / (float)N;
-    // this block's output rows rv + j, j < cnt, = sequence index j + shift
-    int cnt = d.L - rv;
-    if (d.blocks > 1 && cnt > d.block_step) cnt = d.block_step;
-    float *dst = (float *)d.rows + (int64_t)b * d.batch_stride + (int64_t)rv * d.row_stride + d.col_off + c0 + 2 * q;
-    ac_c2 bias2 = {0.f, 0.f};
-    if (d.bias) bias2 = ac_gload<ac_c2>(d.bias + c0 + 2 * q);
-    for (int j0 = threadIdx.x / SEQ; j0 < cnt; j0 += RS * LB) {
-        ac_c2 o[LB];
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+
+    int row, c0;
+    auto locate = [&](int t) __attribute__((always_inline)) {
+        int g;
+        map_block(t, rows, G, row, g);
+        c0 = g * 2 * SEQ;
+    };
+    f32x4 v[EPS];
+    // `rr` = r0 behind an optimisation barrier, renewed per tile: the entry -> (position, partner, frequency) maps
+    // depend on the thread only, and hoisted out of the tile loop they would sit in ~70 registers through every pass
+    int rr = r0;
+    auto issue = [&]() __attribute__((always_inline)) {
+        const float *src = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int j = j0 + u * RS < cnt ? j0 + u * RS : j0;
-            o[u] = seq[phys(j + d.shift)] * inv + bias2;
-            if (d.accumulate) o[u] += ac_gload<ac_c2>(dst + (int64_t)j * d.row_stride);
+        for (int u = 0; u < EPS; ++u) {
+            if (u * RS > halfn) break;
+            const int e = rr + u * RS;
+            int pos, ppos, f;
+            bool pair;
+            half_entry(e <= halfn ? e : 0, d.logn, d.radix3, pos, ppos, f, pair);
+            v[u] = ac_gload<f32x4>(src + (int64_t)f * fstride);
         }
+    };
+    locate(tile);
+    issue();
+    for (;;) {
+        asm volatile("" : "+v"(rr));
 #pragma unroll
-        for (int u = 0; u < LB; ++u)
-            if (j0 + u * RS < cnt) *(ac_c2 *)(dst + (int64_t)(j0 + u * RS) * d.row_stride) = o[u];
+        for (int u = 0; u < EPS; ++u) {
+            if (u * RS > halfn) break;
+            const int e = rr + u * RS;
+            if (e > halfn) continue;
+            int pos, ppos, f;
+            bool pair;
+            half_entry(e, d.logn, d.radix3, pos, ppos, f, pair);
+            ac_c2 zf, zn;
+            tangle(ac_c2{v[u][0], v[u][1]}, ac_c2{v[u][2], v[u][3]}, zf, zn);
+            seq[phys(pos)] = zf;
+            if (pair) seq[phys(ppos)] = zn;
+        }
+        const int b = row / d.blocks, rv = (row - b * d.blocks) * d.block_step, cc0 = c0;
+        tile += W;
+        const bool more = tile < total;
+        if (more) {
+            locate(tile);
+            issue();
+        }
+        fft_inverse<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
+        // this block's output rows rv + j, j < cnt, = sequence index j + shift
+        int cnt = d.L - rv;
+        if (d.blocks > 1 && cnt > d.block_step) cnt = d.block_step;
+        float *dst = (float *)d.rows + (int64_t)b * d.batch_stride + (int64_t)rv * d.row_stride + d.col_off + cc0 + 2 * q;
+        ac_c2 bias2 = {0.f, 0.f};
+        if (d.bias) bias2 = ac_gload<ac_c2>(d.bias + cc0 + 2 * q);
+        for (int j0 = r0; j0 < cnt; j0 += RS * LB) {
+            ac_c2 o[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int j = j0 + u * RS < cnt ? j0 + u * RS : j0;
+                o[u] = seq[phys(j + d.shift)] * inv + bias2;
+                if (d.accumulate) o[u] += ac_gload<ac_c2>(dst + (int64_t)j * d.row_stride);
+            }
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (j0 + u * RS < cnt) *(ac_c2 *)(dst + (int64_t)(j0 + u * RS) * d.row_stride) = o[u];
+        }
+        if (!more) break;
+        __syncthreads();                                         // the image is rewritten
     }
 }
 
@@ -387,6 +480,29 @@ int nseq_for(int n, int channels) {
     return (n <= 512 && channels % 64 == 0) ? 32 : 8;
 }
 
+// The long transforms (N >= 1024, 8 sequences per workgroup) run on 16 waves, one work item per thread and pass: with
+// the CU to itself a workgroup hides the LDS latency of a pass with waves, not with items in flight per thread
+// (stage 2's k = 251 convolution 1.81 -> 1.64 ms, whole step -0.25 ms).  APPLECIDER_FFT_LONG_NARROW=1: the 8-wave form
+// with four items in flight per thread (A/B).
+bool long_wide() {
+    static const bool v = getenv("APPLECIDER_FFT_LONG_NARROW") == nullptr;
+    return v;
+}
+
+// workgroups of a rows launch: every one takes ~4 tiles (latency of the next tile's loads hidden behind the passes of
+// the current one), never fewer workgroups than CUs, a multiple of 8 so that a workgroup's tiles stay on its XCD
+int rows_grid(int total) {
+    static const int tpw = [] {
+        const char *e = getenv("APPLECIDER_FFT_TILES_PER_WG");
+        return e ? atoi(e) : 4;
+    }();
+    if (tpw <= 1 || total <= 256) return total;
+    int w = (total + tpw - 1) / tpw;
+    w = w < 256 ? 256 : w;
+    w = (w + 7) & ~7;
+    return w < total ? w : total;
+}
+
 int rows_check(const ac_fft_rows_desc &d, bool inverse) {
     if (!d.rows || !d.tw || !d.spec || d.B <= 0 || d.L <= 0 || d.C <= 0 || (d.C % 16) || !size_ok(d.logn, d.radix3))
         return AC_EINVAL;
@@ -418,13 +534,16 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     const int rc = rows_check(d, false);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = rows_grid(d.B * d.blocks * (d.C / (2 * ns)));
     if (ns == 128)
         return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<128, 1, true, 1024>, blocks, p, n, 128, st, 1024)
                          : fft_launch(fft_rows_fwd_kernel<128, 1, false, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32)
         return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 1024>, blocks, p, n, 32, st, 1024)
                          : fft_launch(fft_rows_fwd_kernel<32, 1, false, 1024>, blocks, p, n, 32, st, 1024);
+    if (n >= 1024 && long_wide())
+        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 1024>, blocks, p, n, 8, st, 1024)
+                         : fft_launch(fft_rows_fwd_kernel<8, 1, false, 1024>, blocks, p, n, 8, st, 1024);
     if (n >= 1024)
         return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, n, 8, st)
                          : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, n, 8, st);
@@ -440,9 +559,10 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     const int rc = rows_check(d, true);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = d.B * d.blocks * (d.C / (2 * ns));
+    const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = rows_grid(d.B * d.blocks * (d.C / (2 * ns)));
     if (ns == 128) return fft_launch(fft_rows_inv_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
     if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
+    if (n >= 1024 && long_wide()) return fft_launch(fft_rows_inv_kernel<8, 1, 1024>, blocks, p, n, 8, st, 1024);
     if (n >= 1024) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
     return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
 }
