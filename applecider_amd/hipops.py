@@ -1671,6 +1671,10 @@ def _fft_sizes():
                   [((m, 2), 9 << m) for m in range(3, 8)], key=lambda t: (t[1], t[0][1]))
 
 
+# relative cost per point of the >= 1024-point transform kernels in fft_plan (one workgroup per CU, 8 sequences)
+_FFT_LONG_WEIGHT = float(_os.environ.get("APPLECIDER_FFT_LONG_WEIGHT", "1.4"))
+
+
 def fft_plan(L: int, k: int):
     """(logm, radix3, blocks, step) of the transform form of a 'same' Conv1d with k taps on L positions; the transform
     length is N = 2^logm or 3 * 2^logm (a convolution needs L + k // 2 points, rarely a power of two).
@@ -1685,8 +1689,10 @@ def fft_plan(L: int, k: int):
             # (measured, tools/bench_fftconv.py: stage 2's k = 251 costs the same as one 2048-point sequence, 1.91 ms,
             # and as four 512-point windows, 1.96 ms — the window form needs a fifth transform)
             # (the >= 1024-point kernels hold one workgroup per CU and move 2.1 TB/s against 3.6 for the shorter ones:
-            # stage 2's k = 31 costs 1.78 ms as one 1152-point sequence, 1.29 ms as three 384-point windows)
-            best = (N * (1.4 if N >= 1024 else 1.0), logm, r3, 1, L)
+            # stage 2's k = 31 costs 1.78 ms as one 1152-point sequence, 1.29 ms as three 384-point windows; with the
+            # long transforms on 16 waves and the x / dx transforms shared with k = 251 the step is still 0.07 ms
+            # slower with weight 1.0: tools/gpu_r3_ze.sh)
+            best = (N * (_FFT_LONG_WEIGHT if N >= 1024 else 1.0), logm, r3, 1, L)
             break
     if _FFT_OVERLAP_SAVE:
         for (logm, r3), N in _fft_sizes():

@@ -49,6 +49,37 @@ def test_fft_rows_roundtrip_and_spectrum(dev, logn, planes):
     assert _rel(out[:, :, col + 16:col + 16 + Cn], ref + x[:, :, col:col + Cn].double()) <= 2e-6
 
 
+@pytest.mark.parametrize("logn,B,Cn", [((7, 2), 70, 128),    # 1152 points, 8 sequences per workgroup: 560 tiles
+                                       (9, 150, 128),         # 512 points, 32 sequences: 300 tiles (256 + a ragged round)
+                                       ((5, 1), 330, 256),    # 96 points, 128 sequences: 330 tiles
+                                       ((5, 2), 101, 48)])    # 288 points, 8 sequences x 512 threads: 303 tiles, rows % 8 != 0
+@pytest.mark.parametrize("planes", [False, True])
+def test_fft_rows_many_tiles_per_workgroup(dev, logn, B, Cn, planes):
+    """More tiles than workgroups (ac_fft.hip rows_grid): a workgroup walks tiles t, t + grid, ... with the loads of the
+    next one issued before the passes of the current one.  Spectrum against torch.fft.rfft, rows back exactly."""
+    from applecider_amd import hipops as H
+    N = H._fft_size(logn)[2]
+    L, shift = N - 7, 3
+    g = torch.Generator().manual_seed(N + B)
+    x = torch.randn(B, L, Cn, generator=g)
+    xd = x.to(dev)
+    if planes:
+        hi, lo = H.split16(xd)
+        spec = H.fft_rows_fwd(hi, lo, 0, L * Cn, Cn, 0, B, L, Cn, shift, logn)
+        x = (hi.float() + lo.float()).cpu()
+    else:
+        spec = H.fft_rows_fwd(xd, None, 0, L * Cn, Cn, 0, B, L, Cn, shift, logn)
+    seq = torch.zeros(B, N, Cn, dtype=torch.float64)
+    seq[:, shift:shift + L] = x.double()
+    want = torch.fft.rfft(seq, dim=1)
+    got = spec.cpu().double().reshape(N // 2 + 1, B, Cn, 2)
+    got = torch.complex(got[..., 0], got[..., 1]).permute(1, 0, 2)
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
+    out = torch.empty(B, L, Cn, device=dev)
+    H.fft_rows_inv(spec, B, Cn, logn, out, L * Cn, Cn, 0, L, shift, None, False)
+    assert _rel(out, x.double()) <= 2e-6
+
+
 def _ref_conv(x, w, b, dy, k):
     """fp64 reference: y, dx, dw (tap-major [Cout, k*Cin]) of the 'same' Conv1d on channels-last x."""
     xt = x.double().permute(0, 2, 1).requires_grad_(True)
