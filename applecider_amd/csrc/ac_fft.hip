@@ -25,6 +25,47 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Barrier of the transform kernels.  AC_FFT_SYNC_VARIANT (diagnostic builds for the co-residency question of DESIGN
+// section 7-9, tools/dbg_coresidency6.py): 1 = two barriers in a row, 2 = barrier + a short sleep.
+#if defined(AC_FFT_DEBUG)
+#define FFT_SYNC() fft_dbg_sync()
+#elif defined(AC_FFT_SYNC_VARIANT) && AC_FFT_SYNC_VARIANT == 1
+#define FFT_SYNC() do { __syncthreads(); __syncthreads(); } while (0)
+#elif defined(AC_FFT_SYNC_VARIANT) && AC_FFT_SYNC_VARIANT == 2
+#define FFT_SYNC() do { __syncthreads(); __builtin_amdgcn_s_sleep(8); } while (0)
+#else
+#define FFT_SYNC() __syncthreads()
+#endif
+
+#ifdef AC_FFT_DEBUG   // diagnostic build (tools/dbg_coresidency7.py): where does a transform workgroup first see a wrong value?
+__device__ unsigned g_fft_dbg[16];   // [0] LDS != the row just written  [1] two reads of a spectrum source differ
+                                    // [2] read-back of a pass's own store differs  [3] two reads of a pass's source differ
+                                    // [4] two global reads of a row differ  [5] read-back of a spectrum store differs  [6] two reads of a twiddle differ
+                                    // [7] a wave left a barrier before every wave of its workgroup had arrived
+                                    // [8] [9] XOR of the bits of every row element a launch loaded  [10] XOR of the bits it stored
+                                    // [11] a power-of-two twiddle off its analytic value by > 1e-5
+                                    // [12] XOR over (rows written to the image, every pass's reads, every pass's writes but the last): 0 when each
+                                    //      value a stage writes is the value the next stage reads (power-of-two forward transforms)
+extern "C" int ac_fft_debug_read(unsigned *host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_fft_dbg), sizeof(g_fft_dbg)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+// barrier integrity: every wave counts itself in before the barrier; behind it the count must be a whole number of rounds
+__shared__ unsigned g_fft_bar_ctr;
+__device__ __forceinline__ void fft_dbg_sync() {
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_fft_bar_ctr, 1u);
+    __syncthreads();
+    const unsigned c = *(volatile unsigned *)&g_fft_bar_ctr;
+    __syncthreads();
+    if (c % (blockDim.x >> 6) != 0) atomicAdd(&g_fft_dbg[7], 1u);
+}
+#define FFT_DBG_DIFF(a, b) (__float_as_uint((a)[0]) != __float_as_uint((b)[0]) || __float_as_uint((a)[1]) != __float_as_uint((b)[1]))
+#endif
+
 namespace {
 
 using namespace acfft;
@@ -34,7 +75,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TwTable {
     const ac_c2 *tw;   // all levels back to back: level e (transform size N >> e) at element N - (N >> e)
     int n;
+#ifdef AC_FFT_DEBUG
+    __device__ __forceinline__ ac_c2 operator()(int e, int j) const {
+        const ac_c2 a = ac_gload<ac_c2>(tw + (n - (n >> e)) + j);
+        asm volatile("" ::: "memory");
+        const ac_c2 b = *(volatile const ac_c2 *)(tw + (n - (n >> e)) + j);
+        if (FFT_DBG_DIFF(a, b)) atomicAdd(&g_fft_dbg[6], 1u);
+        {
+            float sn, cs;
+            sincosf(-6.283185307179586f * (float)j / (float)(n >> e), &sn, &cs);
+            if (fabsf(a[0] - cs) > 1e-5f || fabsf(a[1] - sn) > 1e-5f) atomicAdd(&g_fft_dbg[11], 1u);
+        }
+        return a;
+    }
+#else
     __device__ __forceinline__ ac_c2 operator()(int e, int j) const { return ac_gload<ac_c2>(tw + (n - (n >> e)) + j); }
+#endif
 };
 
 // One pass over the SEQ sequences of the workgroup.  A thread keeps PASS_U work items in flight: the LDS reads and
@@ -46,7 +102,7 @@ template <int R, bool INVERSE, int SEQ, int PASS_U, int FFT_THREADS>
 __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int logn, int radix3, int pitch, int arg) {
     // logn = log2 of the power-of-two transform; with radix3 = a every sequence is T = 3^a of them (its pieces)
     const int T = pow3(radix3), per = 1 << (logn - R), total = T * SEQ * per, tb = third_base(1, logn);
-    __syncthreads();
+    FFT_SYNC();
     for (int w0 = threadIdx.x; w0 < total; w0 += FFT_THREADS * PASS_U) {
         ac_c2 v[PASS_U][1 << R], tws[PASS_U][R];
         PassItem it[PASS_U];
@@ -65,6 +121,21 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
             else
                 dif_twiddles<R>(tw, arg, it[j].i0, tws[j]);
             pass_load<R>(seq[j], it[j], v[j]);
+#ifdef AC_FFT_DEBUG
+            {
+                ac_c2 v2[1 << R];
+                asm volatile("" ::: "memory");
+                pass_load<R>(seq[j], it[j], v2);
+                unsigned bad = 0;
+                for (int i = 0; i < (1 << R); ++i) bad += FFT_DBG_DIFF(v[j][i], v2[i]);
+                if (bad) atomicAdd(&g_fft_dbg[3], bad);
+                if (!INVERSE && w0 + j * FFT_THREADS < total) {        // [12]: every value one stage writes is read once by the next
+                    unsigned x = 0;
+                    for (int i = 0; i < (1 << R); ++i) x ^= __float_as_uint(v[j][i][0]) ^ (__float_as_uint(v[j][i][1]) * 3u);
+                    atomicXor(&g_fft_dbg[12], x);
+                }
+            }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < PASS_U; ++j) {
@@ -76,6 +147,23 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
 #pragma unroll
         for (int j = 0; j < PASS_U; ++j)
             if (w0 + j * FFT_THREADS < total) pass_store<R>(seq[j], it[j], v[j]);
+#ifdef AC_FFT_DEBUG
+#pragma unroll
+        for (int j = 0; j < PASS_U; ++j)
+            if (w0 + j * FFT_THREADS < total) {
+                ac_c2 v2[1 << R];
+                asm volatile("" ::: "memory");
+                pass_load<R>(seq[j], it[j], v2);
+                unsigned bad = 0;
+                for (int i = 0; i < (1 << R); ++i) bad += FFT_DBG_DIFF(v[j][i], v2[i]);
+                if (bad) atomicAdd(&g_fft_dbg[2], bad);
+                if (!INVERSE && arg + R < logn) {
+                    unsigned x = 0;
+                    for (int i = 0; i < (1 << R); ++i) x ^= __float_as_uint(v[j][i][0]) ^ (__float_as_uint(v[j][i][1]) * 3u);
+                    atomicXor(&g_fft_dbg[12], x);
+                }
+            }
+#endif
     }
 }
 
@@ -90,7 +178,7 @@ __device__ __forceinline__ void fft_radix3_all(ac_c2 *buf, const TwTable &tw, in
         const int st = INVERSE ? radix3 - 1 - k : k;          // stage 0 splits the whole sequence, stage 1 its thirds
         const int s3 = st == 0 ? N / 3 : N / 9, pieces = st == 0 ? 1 : 3, tstride = st == 0 ? 1 : 3;
         const int per = pieces * s3;                          // butterflies per sequence in this stage (= N / 3)
-        __syncthreads();
+        FFT_SYNC();
         for (int w = threadIdx.x; w < SEQ * per; w += FFT_THREADS) {
             const int sq = w / per, u = w - sq * per, pc = u / s3, j = u - pc * s3;
             ac_c2 *seq = buf + sq * pitch + phys(pc * 3 * s3);
@@ -110,7 +198,7 @@ __device__ __forceinline__ void fft_forward(ac_c2 *buf, const TwTable &tw, int l
     if (r0 == 1) fft_pass_all<1, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
     if (r0 == 2) fft_pass_all<2, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, 0);
     for (int s = r0; s < logn; s += 3) fft_pass_all<3, false, SEQ, U, NT>(buf, tw, logn, radix3, pitch, s);
-    __syncthreads();
+    FFT_SYNC();
 }
 // bit-reversed order in -> natural order out (unnormalised inverse)
 template <int SEQ, int U, int NT>
@@ -121,7 +209,7 @@ __device__ __forceinline__ void fft_inverse(ac_c2 *buf, const TwTable &tw, int l
     if (r0 == 1) fft_pass_all<1, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
     if (r0 == 2) fft_pass_all<2, true, SEQ, U, NT>(buf, tw, logn, radix3, pitch, lh);
     if (radix3) fft_radix3_all<true, SEQ, NT>(buf, tw, logn, radix3, pitch);
-    __syncthreads();
+    FFT_SYNC();
 }
 
 // workgroups that share a spectrum row (its channel groups read / write the same 128-byte lines) sit on one XCD
@@ -156,6 +244,15 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
             half_entry(e <= halfn ? e : e0, logn, radix3, pos, ppos, fr[u], pair);
             zf[u] = seq[phys(pos)];
             zn[u] = seq[phys(ppos)];
+#ifdef AC_FFT_DEBUG
+            {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_sleep(4);
+                const ac_c2 a2 = *(volatile const ac_c2 *)&seq[phys(pos)], b2 = *(volatile const ac_c2 *)&seq[phys(ppos)];
+                const unsigned bad = FFT_DBG_DIFF(zf[u], a2) + FFT_DBG_DIFF(zn[u], b2);
+                if (bad) atomicAdd(&g_fft_dbg[1], bad);
+            }
+#endif
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -163,6 +260,16 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
             ac_c2 x1, x2;
             untangle(zf[u], zn[u], x1, x2);
             *(f32x4 *)(dst + (int64_t)fr[u] * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
+#ifdef AC_FFT_DEBUG
+            {
+                __threadfence();
+                const f32x4 r = *(volatile const f32x4 *)(dst + (int64_t)fr[u] * fstride);
+                const unsigned bad = (__float_as_uint(r[0]) != __float_as_uint(x1[0])) + (__float_as_uint(r[1]) != __float_as_uint(x1[1])) +
+                                     (__float_as_uint(r[2]) != __float_as_uint(x2[0])) + (__float_as_uint(r[3]) != __float_as_uint(x2[1]));
+                if (bad) atomicAdd(&g_fft_dbg[5], bad);
+                atomicXor(&g_fft_dbg[10], __float_as_uint(x1[0]) ^ __float_as_uint(x1[1]) ^ __float_as_uint(x2[0]) ^ __float_as_uint(x2[1]));
+            }
+#endif
         }
     }
 }
@@ -190,6 +297,10 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
     const int64_t fstride = (int64_t)rows * (2 * d.C);
     int tile = blockIdx.x;
     if (tile >= total) return;
+#ifdef AC_FFT_DEBUG
+    if (threadIdx.x == 0) g_fft_bar_ctr = 0u;
+    __syncthreads();
+#endif
 
     // sequence indices [n0, n1) of tile `t` take the rows l = rv + n - shift; everything else is zero
     int row, c0, n0, n1;
@@ -222,6 +333,17 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
                 const ac_c2 v = ac_gload<ac_c2>((const float *)d.rows + a);
                 z[u].a = __float_as_uint(v[0]);
                 z[u].b = __float_as_uint(v[1]);
+#ifdef AC_FFT_DEBUG
+                {
+                    asm volatile("" ::: "memory");
+                    const ac_c2 v2 = *(volatile const ac_c2 *)((const float *)d.rows + a);
+                    if (FFT_DBG_DIFF(v, v2)) atomicAdd(&g_fft_dbg[4], 1u);
+                    if (j < cnt) {
+                        atomicXor(&g_fft_dbg[8], z[u].a);
+                        atomicXor(&g_fft_dbg[9], z[u].b);
+                    }
+                }
+#endif
             }
         }
     };
@@ -243,6 +365,14 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
             else
                 v = ac_c2{__uint_as_float(z[u].a), __uint_as_float(z[u].b)};
             seq[phys(n0 + j)] = v;
+#ifdef AC_FFT_DEBUG
+            {
+                asm volatile("" ::: "memory");
+                const ac_c2 b2 = *(volatile const ac_c2 *)&seq[phys(n0 + j)];
+                if (FFT_DBG_DIFF(v, b2)) atomicAdd(&g_fft_dbg[0], 1u);
+                atomicXor(&g_fft_dbg[12], __float_as_uint(v[0]) ^ (__float_as_uint(v[1]) * 3u));
+            }
+#endif
         }
         float *dst = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
         tile += W;
@@ -254,7 +384,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
         fft_forward<SEQ, U, FFT_THREADS>(fbuf, tw, d.logn, d.radix3, pitch);
         spectrum_store<SEQ, SB, FFT_THREADS>(seq, dst, fstride, d.logn, d.radix3);
         if (!more) break;
-        __syncthreads();                                         // the image is rewritten
+        FFT_SYNC();                                         // the image is rewritten
     }
 }
 
@@ -368,7 +498,7 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
                 if (j0 + u * RS < cnt) *(ac_c2 *)(dst + (int64_t)(j0 + u * RS) * d.row_stride) = o[u];
         }
         if (!more) break;
-        __syncthreads();                                         // the image is rewritten
+        FFT_SYNC();                                         // the image is rewritten
     }
 }
 
@@ -444,16 +574,24 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
 template <typename K, typename P>
 int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream, int FFT_THREADS = 512) {
     // EVERY transform workgroup asks for the whole LDS of a CU (160 KB), so that it shares its CU with nothing.
-    // Measured (tools/dbg_coresidency*.py): beside workgroups of OTHER kernels (the attention kernels,
-    // the photometry forward, the image backward; never the gather-GEMM, LayerNorm or its own kind) a transform
-    // workgroup returns a few wrong values — the imaginary half of some partner elements read after the last pass —
-    // in up to 100 % of the launches, eagerly and in graphs, while LDS allocations do not overlap (tools/lds_probe.hip)
-    // and the kernel is bit-exact alone, at any batch size.  With the CU to itself: 0 of 100.  Cause unexplained.
+    // History (profiles/r03_fft_coresidency_root_cause.txt): beside workgroups of certain OTHER kernels
+    // (attention, the photometry forward, the image backward) a transform workgroup computed wrong imaginary parts in up to
+    // 100 % of the launches.  In-kernel self-checks (-DAC_FFT_DEBUG) found inputs, twiddles, LDS traffic and barriers
+    // right and the arithmetic wrong: the HIGH halves of packed-fp32 instructions (v_pk_add/mul/fma_f32), which only
+    // this file's float2 math produced.  The library is built without them now (Makefile NOPK) and is exact with
+    // shared CUs too (APPLECIDER_FFT_SHARED_CU=1: the exact request); the whole-CU request stays as a second line of
+    // defence, at no measurable cost.
     size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
     static const bool shared_cu = getenv("APPLECIDER_FFT_SHARED_CU") != nullptr;      // diagnostic: the exact request
     if (!shared_cu) lds = 160 * 1024;
     {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef AC_FFT_DEBUG
+        const int max_dyn = 160 * 1024 - 256;      // the diagnostic build owns 4 bytes of static LDS
+        if (lds > (size_t)max_dyn) lds = max_dyn;
+#else
+        const int max_dyn = 160 * 1024;
+#endif
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
         if (e != hipSuccess) return -(int)e - 2000;
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FFT_THREADS), lds, stream, p);
