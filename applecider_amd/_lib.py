@@ -77,7 +77,7 @@ class FftRowsDesc(C.Structure):
                 ("bias", C.c_void_p), ("batch_stride", C.c_int64), ("row_stride", C.c_int64),
                 ("col_off", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("logn", C.c_int32),
                 ("radix3", C.c_int32), ("blocks", C.c_int32), ("block_step", C.c_int32), ("shift", C.c_int32),
-                ("n_lo", C.c_int32), ("n_hi", C.c_int32), ("accumulate", C.c_int32)]
+                ("n_lo", C.c_int32), ("n_hi", C.c_int32), ("accumulate", C.c_int32), ("lds_exact", C.c_int32)]
 
 
 class TowerDesc(C.Structure):
@@ -181,7 +181,7 @@ SIGNATURES = {
     "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "ac_fft_taps_inv": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 _RESTYPES = {"ac_strerror": C.c_char_p}
 
 _lib = None

@@ -22,49 +22,11 @@
 // N = 2048) or, for N <= 128, 32 of them (64 channels).  fp32 throughout: 2-5e-7 of the direct convolution.
 #include "ac_common.h"
 #include "ac_fft_core.h"
-#include <cstdlib>
 #include <type_traits>
 
-// Barrier of the transform kernels.  AC_FFT_SYNC_VARIANT (diagnostic builds for the co-residency question of DESIGN
-// section 7-9, tools/dbg_coresidency6.py): 1 = two barriers in a row, 2 = barrier + a short sleep.
-#if defined(AC_FFT_DEBUG)
-#define FFT_SYNC() fft_dbg_sync()
-#elif defined(AC_FFT_SYNC_VARIANT) && AC_FFT_SYNC_VARIANT == 1
-#define FFT_SYNC() do { __syncthreads(); __syncthreads(); } while (0)
-#elif defined(AC_FFT_SYNC_VARIANT) && AC_FFT_SYNC_VARIANT == 2
-#define FFT_SYNC() do { __syncthreads(); __builtin_amdgcn_s_sleep(8); } while (0)
-#else
+// Barrier of the transform kernels (one name so that tools/fft_debug.patch, the diagnostic build of DESIGN section 7-9,
+// can instrument it).
 #define FFT_SYNC() __syncthreads()
-#endif
-
-#ifdef AC_FFT_DEBUG   // diagnostic build (tools/dbg_coresidency7.py): where does a transform workgroup first see a wrong value?
-__device__ unsigned g_fft_dbg[16];   // [0] LDS != the row just written  [1] two reads of a spectrum source differ
-                                    // [2] read-back of a pass's own store differs  [3] two reads of a pass's source differ
-                                    // [4] two global reads of a row differ  [5] read-back of a spectrum store differs  [6] two reads of a twiddle differ
-                                    // [7] a wave left a barrier before every wave of its workgroup had arrived
-                                    // [8] [9] XOR of the bits of every row element a launch loaded  [10] XOR of the bits it stored
-                                    // [11] a power-of-two twiddle off its analytic value by > 1e-5
-                                    // [12] XOR over (rows written to the image, every pass's reads, every pass's writes but the last): 0 when each
-                                    //      value a stage writes is the value the next stage reads (power-of-two forward transforms)
-extern "C" int ac_fft_debug_read(unsigned *host16, int reset) {
-    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_fft_dbg), sizeof(g_fft_dbg)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-// barrier integrity: every wave counts itself in before the barrier; behind it the count must be a whole number of rounds
-__shared__ unsigned g_fft_bar_ctr;
-__device__ __forceinline__ void fft_dbg_sync() {
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_fft_bar_ctr, 1u);
-    __syncthreads();
-    const unsigned c = *(volatile unsigned *)&g_fft_bar_ctr;
-    __syncthreads();
-    if (c % (blockDim.x >> 6) != 0) atomicAdd(&g_fft_dbg[7], 1u);
-}
-#define FFT_DBG_DIFF(a, b) (__float_as_uint((a)[0]) != __float_as_uint((b)[0]) || __float_as_uint((a)[1]) != __float_as_uint((b)[1]))
-#endif
 
 namespace {
 
@@ -75,22 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TwTable {
     const ac_c2 *tw;   // all levels back to back: level e (transform size N >> e) at element N - (N >> e)
     int n;
-#ifdef AC_FFT_DEBUG
-    __device__ __forceinline__ ac_c2 operator()(int e, int j) const {
-        const ac_c2 a = ac_gload<ac_c2>(tw + (n - (n >> e)) + j);
-        asm volatile("" ::: "memory");
-        const ac_c2 b = *(volatile const ac_c2 *)(tw + (n - (n >> e)) + j);
-        if (FFT_DBG_DIFF(a, b)) atomicAdd(&g_fft_dbg[6], 1u);
-        {
-            float sn, cs;
-            sincosf(-6.283185307179586f * (float)j / (float)(n >> e), &sn, &cs);
-            if (fabsf(a[0] - cs) > 1e-5f || fabsf(a[1] - sn) > 1e-5f) atomicAdd(&g_fft_dbg[11], 1u);
-        }
-        return a;
-    }
-#else
     __device__ __forceinline__ ac_c2 operator()(int e, int j) const { return ac_gload<ac_c2>(tw + (n - (n >> e)) + j); }
-#endif
 };
 
 // One pass over the SEQ sequences of the workgroup.  A thread keeps PASS_U work items in flight: the LDS reads and
@@ -121,21 +68,6 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
             else
                 dif_twiddles<R>(tw, arg, it[j].i0, tws[j]);
             pass_load<R>(seq[j], it[j], v[j]);
-#ifdef AC_FFT_DEBUG
-            {
-                ac_c2 v2[1 << R];
-                asm volatile("" ::: "memory");
-                pass_load<R>(seq[j], it[j], v2);
-                unsigned bad = 0;
-                for (int i = 0; i < (1 << R); ++i) bad += FFT_DBG_DIFF(v[j][i], v2[i]);
-                if (bad) atomicAdd(&g_fft_dbg[3], bad);
-                if (!INVERSE && w0 + j * FFT_THREADS < total) {        // [12]: every value one stage writes is read once by the next
-                    unsigned x = 0;
-                    for (int i = 0; i < (1 << R); ++i) x ^= __float_as_uint(v[j][i][0]) ^ (__float_as_uint(v[j][i][1]) * 3u);
-                    atomicXor(&g_fft_dbg[12], x);
-                }
-            }
-#endif
         }
 #pragma unroll
         for (int j = 0; j < PASS_U; ++j) {
@@ -147,23 +79,6 @@ __device__ __forceinline__ void fft_pass_all(ac_c2 *buf, const TwTable &tw, int 
 #pragma unroll
         for (int j = 0; j < PASS_U; ++j)
             if (w0 + j * FFT_THREADS < total) pass_store<R>(seq[j], it[j], v[j]);
-#ifdef AC_FFT_DEBUG
-#pragma unroll
-        for (int j = 0; j < PASS_U; ++j)
-            if (w0 + j * FFT_THREADS < total) {
-                ac_c2 v2[1 << R];
-                asm volatile("" ::: "memory");
-                pass_load<R>(seq[j], it[j], v2);
-                unsigned bad = 0;
-                for (int i = 0; i < (1 << R); ++i) bad += FFT_DBG_DIFF(v[j][i], v2[i]);
-                if (bad) atomicAdd(&g_fft_dbg[2], bad);
-                if (!INVERSE && arg + R < logn) {
-                    unsigned x = 0;
-                    for (int i = 0; i < (1 << R); ++i) x ^= __float_as_uint(v[j][i][0]) ^ (__float_as_uint(v[j][i][1]) * 3u);
-                    atomicXor(&g_fft_dbg[12], x);
-                }
-            }
-#endif
     }
 }
 
@@ -244,15 +159,6 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
             half_entry(e <= halfn ? e : e0, logn, radix3, pos, ppos, fr[u], pair);
             zf[u] = seq[phys(pos)];
             zn[u] = seq[phys(ppos)];
-#ifdef AC_FFT_DEBUG
-            {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_sleep(4);
-                const ac_c2 a2 = *(volatile const ac_c2 *)&seq[phys(pos)], b2 = *(volatile const ac_c2 *)&seq[phys(ppos)];
-                const unsigned bad = FFT_DBG_DIFF(zf[u], a2) + FFT_DBG_DIFF(zn[u], b2);
-                if (bad) atomicAdd(&g_fft_dbg[1], bad);
-            }
-#endif
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -260,16 +166,6 @@ __device__ __forceinline__ void spectrum_store(const ac_c2 *seq, float *dst, int
             ac_c2 x1, x2;
             untangle(zf[u], zn[u], x1, x2);
             *(f32x4 *)(dst + (int64_t)fr[u] * fstride) = f32x4{x1[0], x1[1], x2[0], x2[1]};
-#ifdef AC_FFT_DEBUG
-            {
-                __threadfence();
-                const f32x4 r = *(volatile const f32x4 *)(dst + (int64_t)fr[u] * fstride);
-                const unsigned bad = (__float_as_uint(r[0]) != __float_as_uint(x1[0])) + (__float_as_uint(r[1]) != __float_as_uint(x1[1])) +
-                                     (__float_as_uint(r[2]) != __float_as_uint(x2[0])) + (__float_as_uint(r[3]) != __float_as_uint(x2[1]));
-                if (bad) atomicAdd(&g_fft_dbg[5], bad);
-                atomicXor(&g_fft_dbg[10], __float_as_uint(x1[0]) ^ __float_as_uint(x1[1]) ^ __float_as_uint(x2[0]) ^ __float_as_uint(x2[1]));
-            }
-#endif
         }
     }
 }
@@ -297,10 +193,6 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
     const int64_t fstride = (int64_t)rows * (2 * d.C);
     int tile = blockIdx.x;
     if (tile >= total) return;
-#ifdef AC_FFT_DEBUG
-    if (threadIdx.x == 0) g_fft_bar_ctr = 0u;
-    __syncthreads();
-#endif
 
     // sequence indices [n0, n1) of tile `t` take the rows l = rv + n - shift; everything else is zero
     int row, c0, n0, n1;
@@ -333,17 +225,6 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
                 const ac_c2 v = ac_gload<ac_c2>((const float *)d.rows + a);
                 z[u].a = __float_as_uint(v[0]);
                 z[u].b = __float_as_uint(v[1]);
-#ifdef AC_FFT_DEBUG
-                {
-                    asm volatile("" ::: "memory");
-                    const ac_c2 v2 = *(volatile const ac_c2 *)((const float *)d.rows + a);
-                    if (FFT_DBG_DIFF(v, v2)) atomicAdd(&g_fft_dbg[4], 1u);
-                    if (j < cnt) {
-                        atomicXor(&g_fft_dbg[8], z[u].a);
-                        atomicXor(&g_fft_dbg[9], z[u].b);
-                    }
-                }
-#endif
             }
         }
     };
@@ -365,14 +246,6 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 && FFT_THREADS >= 1024 ? 4 : 2)
             else
                 v = ac_c2{__uint_as_float(z[u].a), __uint_as_float(z[u].b)};
             seq[phys(n0 + j)] = v;
-#ifdef AC_FFT_DEBUG
-            {
-                asm volatile("" ::: "memory");
-                const ac_c2 b2 = *(volatile const ac_c2 *)&seq[phys(n0 + j)];
-                if (FFT_DBG_DIFF(v, b2)) atomicAdd(&g_fft_dbg[0], 1u);
-                atomicXor(&g_fft_dbg[12], __float_as_uint(v[0]) ^ (__float_as_uint(v[1]) * 3u));
-            }
-#endif
         }
         float *dst = d.spec + (int64_t)row * (2 * d.C) + 2 * (c0 + 2 * q);
         tile += W;
@@ -571,30 +444,24 @@ __global__ __launch_bounds__(FFT_THREADS, U == 1 ? 8 : 2) void fft_taps_inv_kern
     }
 }
 
-template <typename K, typename P>
-int fft_launch(K kernel, int blocks, const P &p, int n, int nseq, hipStream_t stream, int FFT_THREADS = 512) {
+template <auto KERNEL, typename P>
+int fft_launch(int blocks, const P &p, int n, int nseq, hipStream_t stream, int FFT_THREADS = 512, bool lds_exact = false) {
     // EVERY transform workgroup asks for the whole LDS of a CU (160 KB), so that it shares its CU with nothing.
     // History (profiles/r03_fft_coresidency_root_cause.txt): beside workgroups of certain OTHER kernels
     // (attention, the photometry forward, the image backward) a transform workgroup computed wrong imaginary parts in up to
-    // 100 % of the launches.  In-kernel self-checks (-DAC_FFT_DEBUG) found inputs, twiddles, LDS traffic and barriers
+    // 100 % of the launches.  In-kernel self-checks (tools/fft_debug.patch) found inputs, twiddles, LDS traffic and barriers
     // right and the arithmetic wrong: the HIGH halves of packed-fp32 instructions (v_pk_add/mul/fma_f32), which only
-    // this file's float2 math produced.  The library is built without them now (Makefile NOPK) and is exact with
-    // shared CUs too (APPLECIDER_FFT_SHARED_CU=1: the exact request); the whole-CU request stays as a second line of
-    // defence, at no measurable cost.
-    size_t lds = (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2);
-    static const bool shared_cu = getenv("APPLECIDER_FFT_SHARED_CU") != nullptr;      // diagnostic: the exact request
-    if (!shared_cu) lds = 160 * 1024;
-    {
-#ifdef AC_FFT_DEBUG
-        const int max_dyn = 160 * 1024 - 256;      // the diagnostic build owns 4 bytes of static LDS
-        if (lds > (size_t)max_dyn) lds = max_dyn;
-#else
-        const int max_dyn = 160 * 1024;
-#endif
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
+    // this file's float2 math produced.  The library is built without them (Makefile NOPK; tests/test_no_packed_fp32.py
+    // disassembles the code objects) and is exact with shared CUs too (ac_fft_rows_desc.lds_exact = 1: the exact
+    // request, diagnostic); the whole-CU request stays as a second line of defence, at no measurable cost.
+    const size_t lds = lds_exact ? (size_t)nseq * seq_pitch_n(n, nseq) * sizeof(ac_c2) : (size_t)160 * 1024;
+    static bool configured = false;   // once per kernel instance (benign race: same value from any thread)
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FFT_THREADS), lds, stream, p);
+    hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(FFT_THREADS), lds, stream, p);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -620,21 +487,14 @@ int nseq_for(int n, int channels) {
 
 // The long transforms (N >= 1024, 8 sequences per workgroup) run on 16 waves, one work item per thread and pass: with
 // the CU to itself a workgroup hides the LDS latency of a pass with waves, not with items in flight per thread
-// (stage 2's k = 251 convolution 1.81 -> 1.64 ms, whole step -0.25 ms).  APPLECIDER_FFT_LONG_NARROW=1: the 8-wave form
-// with four items in flight per thread (A/B).
-bool long_wide() {
-    static const bool v = getenv("APPLECIDER_FFT_LONG_NARROW") == nullptr;
-    return v;
-}
+// (stage 2's k = 251 convolution 1.81 -> 1.64 ms, whole step -0.25 ms against the 8-wave form with four items in
+// flight per thread, which the taps transforms keep).
 
 // workgroups of a rows launch: every one takes ~4 tiles (latency of the next tile's loads hidden behind the passes of
 // the current one), never fewer workgroups than CUs, a multiple of 8 so that a workgroup's tiles stay on its XCD
 int rows_grid(int total) {
-    static const int tpw = [] {
-        const char *e = getenv("APPLECIDER_FFT_TILES_PER_WG");
-        return e ? atoi(e) : 4;
-    }();
-    if (tpw <= 1 || total <= 256) return total;
+    constexpr int tpw = 4;
+    if (total <= 256) return total;
     int w = (total + tpw - 1) / tpw;
     w = w < 256 ? 256 : w;
     w = (w + 7) & ~7;
@@ -672,21 +532,19 @@ extern "C" int ac_fft_rows_fwd(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     const int rc = rows_check(d, false);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool ex = d.lds_exact != 0;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = rows_grid(d.B * d.blocks * (d.C / (2 * ns)));
     if (ns == 128)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<128, 1, true, 1024>, blocks, p, n, 128, st, 1024)
-                         : fft_launch(fft_rows_fwd_kernel<128, 1, false, 1024>, blocks, p, n, 128, st, 1024);
+        return d.rows_lo ? fft_launch<fft_rows_fwd_kernel<128, 1, true, 1024>>(blocks, p, n, 128, st, 1024, ex)
+                         : fft_launch<fft_rows_fwd_kernel<128, 1, false, 1024>>(blocks, p, n, 128, st, 1024, ex);
     if (ns == 32)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<32, 1, true, 1024>, blocks, p, n, 32, st, 1024)
-                         : fft_launch(fft_rows_fwd_kernel<32, 1, false, 1024>, blocks, p, n, 32, st, 1024);
-    if (n >= 1024 && long_wide())
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 1024>, blocks, p, n, 8, st, 1024)
-                         : fft_launch(fft_rows_fwd_kernel<8, 1, false, 1024>, blocks, p, n, 8, st, 1024);
+        return d.rows_lo ? fft_launch<fft_rows_fwd_kernel<32, 1, true, 1024>>(blocks, p, n, 32, st, 1024, ex)
+                         : fft_launch<fft_rows_fwd_kernel<32, 1, false, 1024>>(blocks, p, n, 32, st, 1024, ex);
     if (n >= 1024)
-        return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 4, true, 512>, blocks, p, n, 8, st)
-                         : fft_launch(fft_rows_fwd_kernel<8, 4, false, 512>, blocks, p, n, 8, st);
-    return d.rows_lo ? fft_launch(fft_rows_fwd_kernel<8, 1, true, 512>, blocks, p, n, 8, st)
-                     : fft_launch(fft_rows_fwd_kernel<8, 1, false, 512>, blocks, p, n, 8, st);
+        return d.rows_lo ? fft_launch<fft_rows_fwd_kernel<8, 1, true, 1024>>(blocks, p, n, 8, st, 1024, ex)
+                         : fft_launch<fft_rows_fwd_kernel<8, 1, false, 1024>>(blocks, p, n, 8, st, 1024, ex);
+    return d.rows_lo ? fft_launch<fft_rows_fwd_kernel<8, 1, true, 512>>(blocks, p, n, 8, st, 512, ex)
+                     : fft_launch<fft_rows_fwd_kernel<8, 1, false, 512>>(blocks, p, n, 8, st, 512, ex);
 }
 
 extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
@@ -697,12 +555,12 @@ extern "C" int ac_fft_rows_inv(const ac_fft_rows_desc *dp, ac_stream_t stream) {
     const int rc = rows_check(d, true);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool ex = d.lds_exact != 0;
     const int n = size_n(d.logn, d.radix3), ns = nseq_for(n, d.C), blocks = rows_grid(d.B * d.blocks * (d.C / (2 * ns)));
-    if (ns == 128) return fft_launch(fft_rows_inv_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
-    if (ns == 32) return fft_launch(fft_rows_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
-    if (n >= 1024 && long_wide()) return fft_launch(fft_rows_inv_kernel<8, 1, 1024>, blocks, p, n, 8, st, 1024);
-    if (n >= 1024) return fft_launch(fft_rows_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
-    return fft_launch(fft_rows_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
+    if (ns == 128) return fft_launch<fft_rows_inv_kernel<128, 1, 1024>>(blocks, p, n, 128, st, 1024, ex);
+    if (ns == 32) return fft_launch<fft_rows_inv_kernel<32, 1, 1024>>(blocks, p, n, 32, st, 1024, ex);
+    if (n >= 1024) return fft_launch<fft_rows_inv_kernel<8, 1, 1024>>(blocks, p, n, 8, st, 1024, ex);
+    return fft_launch<fft_rows_inv_kernel<8, 1, 512>>(blocks, p, n, 8, st, 512, ex);
 }
 
 extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3,
@@ -715,10 +573,10 @@ extern "C" int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_
     p.src = w; p.dst = hblock; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 128) return fft_launch(fft_taps_fwd_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
-    if (ns == 32) return fft_launch(fft_taps_fwd_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
-    if (n >= 1024) return fft_launch(fft_taps_fwd_kernel<8, 4, 512>, blocks, p, n, 8, st);
-    return fft_launch(fft_taps_fwd_kernel<8, 1, 512>, blocks, p, n, 8, st);
+    if (ns == 128) return fft_launch<fft_taps_fwd_kernel<128, 1, 1024>>(blocks, p, n, 128, st, 1024);
+    if (ns == 32) return fft_launch<fft_taps_fwd_kernel<32, 1, 1024>>(blocks, p, n, 32, st, 1024);
+    if (n >= 1024) return fft_launch<fft_taps_fwd_kernel<8, 4, 512>>(blocks, p, n, 8, st);
+    return fft_launch<fft_taps_fwd_kernel<8, 1, 512>>(blocks, p, n, 8, st);
 }
 
 extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3,
@@ -731,8 +589,8 @@ extern "C" int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_
     p.src = m; p.dst = dw; p.tw = (const ac_c2 *)tw; p.Cout = Cout; p.Cin = Cin; p.k = k; p.logn = logn; p.radix3 = radix3;
     hipStream_t st = (hipStream_t)stream;
     const int n = size_n(logn, radix3), ns = nseq_for(n, Cin), blocks = Cout * (Cin / (2 * ns));
-    if (ns == 128) return fft_launch(fft_taps_inv_kernel<128, 1, 1024>, blocks, p, n, 128, st, 1024);
-    if (ns == 32) return fft_launch(fft_taps_inv_kernel<32, 1, 1024>, blocks, p, n, 32, st, 1024);
-    if (n >= 1024) return fft_launch(fft_taps_inv_kernel<8, 4, 512>, blocks, p, n, 8, st);
-    return fft_launch(fft_taps_inv_kernel<8, 1, 512>, blocks, p, n, 8, st);
+    if (ns == 128) return fft_launch<fft_taps_inv_kernel<128, 1, 1024>>(blocks, p, n, 128, st, 1024);
+    if (ns == 32) return fft_launch<fft_taps_inv_kernel<32, 1, 1024>>(blocks, p, n, 32, st, 1024);
+    if (n >= 1024) return fft_launch<fft_taps_inv_kernel<8, 4, 512>>(blocks, p, n, 8, st);
+    return fft_launch<fft_taps_inv_kernel<8, 1, 512>>(blocks, p, n, 8, st);
 }

@@ -1485,6 +1485,10 @@ static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int6
     p.tiles_n = (d.N + BN - 1) / BN;
     p.nkt = (d.K + BK - 1) / BK;
     p.kt_per_split = (p.nkt + d.split_k - 1) / d.split_k;
+    // a K piece without tiles returns before it stores: in slab form its slab would stay unwritten and
+    // ac_splitk_reduce would sum uninitialised memory - the caller must pass a split_k whose last piece is not empty
+    // (split_k = ceil(nkt / ceil(nkt / wanted)); hipops._exact_split)
+    if (slabs && (int64_t)(d.split_k - 1) * p.kt_per_split >= p.nkt) return AC_EINVAL;
     dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
     const size_t lds_f32 = 4 * TILE_FLOATS * sizeof(float);  // 64 KB
     const size_t lds_bf16 = 4 * TILE_FLOATS * sizeof(short); // 32 KB

@@ -525,7 +525,7 @@ def _split_for(m_out: int, n_out: int, k_red: int) -> int:
     nkt = -(-k_red // 64)
     if x3_mode():
         # split-bf16 kernel: 32-deep K tiles and ~3x the matrix-core time per tile — workgroups amortise their
-        # prologue over half as many K rows (measured, tools/exp_tn_split.py: 1024x1536x8192 178 -> 139 us,
+        # prologue over half as many K rows (measured, tools/archive/exp_tn_split.py: 1024x1536x8192 178 -> 139 us,
         # 512x128x66048 80 -> 72 us, 512x1028x262144 1417 -> 1333 us)
         split = max(1, min(2048 // tiles, nkt // 32))
         want = 512 if nkt >= 256 else 256      # short reductions: one workgroup per CU is enough
@@ -644,7 +644,16 @@ def _small_grid_split(M: int, N: int, K: int) -> int:
     nkt = K // 32
     if tiles > 128 or nkt < 16:
         return 1
-    return max(1, min(512 // tiles, nkt // 8))
+    return _exact_split(nkt, max(1, min(512 // tiles, nkt // 8)))
+
+
+def _exact_split(nkt: int, split: int) -> int:
+    """The largest split <= `split` whose LAST piece still holds a K tile.  The library gives every piece
+    ceil(nkt / split) tiles; a piece that starts beyond the last tile returns without storing, and in slab form
+    (accumulate = 3) its slab would reach ac_splitk_reduce unwritten (M, N <= 128, K = 4160 -> nkt = 130,
+    split 16 -> 9 tiles per piece -> piece 15 starts at tile 135).  ac_gemm refuses such a launch with AC_EINVAL."""
+    per = -(-nkt // max(1, split))
+    return -(-nkt // per)
 
 
 # --------------------------------------------------------------------------- Linear
@@ -1691,7 +1700,7 @@ def fft_plan(L: int, k: int):
             # (the >= 1024-point kernels hold one workgroup per CU and move 2.1 TB/s against 3.6 for the shorter ones:
             # stage 2's k = 31 costs 1.78 ms as one 1152-point sequence, 1.29 ms as three 384-point windows; with the
             # long transforms on 16 waves and the x / dx transforms shared with k = 251 the step is still 0.07 ms
-            # slower with weight 1.0: tools/gpu_r3_ze.sh)
+            # slower with weight 1.0: tools/archive/gpu_r3_ze.sh)
             best = (N * (_FFT_LONG_WEIGHT if N >= 1024 else 1.0), logm, r3, 1, L)
             break
     if _FFT_OVERLAP_SAVE:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AC_ABI_VERSION 4
+#define AC_ABI_VERSION 5
 
 #define AC_OK 0
 #define AC_EINVAL (-22)     /* bad argument / unsupported shape            */
@@ -628,6 +628,8 @@ typedef struct ac_fft_rows_desc {
     int32_t blocks, block_step, shift;
     int32_t n_lo, n_hi;  /* forward only */
     int32_t accumulate;  /* inverse only: rows += */
+    int32_t lds_exact;   /* 0 (default): every transform workgroup requests a whole CU's LDS and shares its CU with
+                            nothing; 1 (diagnostic): the exact request, workgroups of other kernels may share the CU */
 } ac_fft_rows_desc;
 int ac_gemm_batched(const ac_gemm_desc *d, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c, ac_stream_t stream);
 int ac_fft_rows_fwd(const ac_fft_rows_desc *d, ac_stream_t stream);

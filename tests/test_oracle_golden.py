@@ -386,7 +386,7 @@ def test_cabi_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(lib, name), (path, name)
     loaded = _lib.load()
-    assert loaded.ac_abi_version() == _lib.ABI_VERSION == 4
+    assert loaded.ac_abi_version() == _lib.ABI_VERSION == 5
     assert b"invalid" in loaded.ac_strerror(-22)
     # argument validation happens before any launch, so it can be exercised without a GPU
     assert loaded.ac_gemm(None, None) == -22

@@ -1,14 +1,33 @@
 #!/bin/bash
-# diagnostic build of ac_fft.hip (-DAC_FFT_DEBUG: in-kernel self-checks) linked with the product objects ->
-# tools/libac_dbg_checks.so (not part of the product; run before tools/dbg_coresidency7.py).  The barrier variants of
-# tools/gpu_r3_zf.sh are the same recipe with -DAC_FFT_SYNC_VARIANT=1 / 2 -> libac_dbg_sync1.so / libac_dbg_sync2.so; to
-# see the fault itself again, build the product library with `make NOPK=` (packed fp32 back on) and run
-# tools/dbg_coresidency6.py with APPLECIDER_FFT_SHARED_CU=1.  NOTE: FLAGS below deliberately leave packed fp32 ON for
-# ac_fft.hip — the self-checks only mean something while the fault is present.
+# Diagnostic builds of the transform kernels for the co-residency question of DESIGN section 7-9 (not part of the
+# product; the probes that load them are tools/archive/dbg_coresidency6.py / 7.py).  The instrumented source is the
+# product's ac_fft.hip + tools/fft_debug.patch (in-kernel self-checks, barrier variants), applied to a temporary copy.
+#   usage: tools/build_fft_dbg.sh <variant>      -> tools/libac_dbg_<variant>.so
+#     checks  -DAC_FFT_DEBUG: self-checks of every load / LDS hand-over / barrier; packed fp32 ON (the checks only mean
+#             something while the fault is present)
+#     sync1   two barriers in a row at every phase boundary, packed fp32 ON
+#     sync2   barrier + s_sleep, packed fp32 ON
+#     nopk    the instrumented source with the product's flags (no packed fp32): the fault is gone
+# The diagnostic probes ask for the exact LDS size (ac_fft_rows_desc.lds_exact = 1) so that workgroups share their CU.
 set -e
-C=/root/repo/applecider_amd/csrc
+V=${1:?variant: checks | sync1 | sync2 | nopk}
+R=$(cd "$(dirname "$0")/.." && pwd)
+C=$R/applecider_amd/csrc
+T=$(mktemp -d)
+mkdir -p $T/applecider_amd/csrc $T/include
+cp $C/ac_fft.hip $C/ac_fft_core.h $C/ac_common.h $T/applecider_amd/csrc/
+cp $R/include/applecider_hip.h $T/include/
+(cd $T && patch -s -p1 < $R/tools/fft_debug.patch)
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-pass-failed -fno-slp-vectorize"
+case $V in
+  checks) FLAGS="$FLAGS -DAC_FFT_DEBUG" ;;
+  sync1)  FLAGS="$FLAGS -DAC_FFT_SYNC_VARIANT=1" ;;
+  sync2)  FLAGS="$FLAGS -DAC_FFT_SYNC_VARIANT=2" ;;
+  nopk)   FLAGS="$FLAGS -DAC_FFT_DEBUG -Xclang -target-feature -Xclang -packed-fp32-ops" ;;
+  *) echo "unknown variant $V"; exit 2 ;;
+esac
 OBJS=$(ls $C/*.o | grep -v "/f16_" | grep -v "/ac_fft.o")
-/opt/rocm/bin/hipcc $FLAGS -DAC_FFT_DEBUG -c $C/ac_fft.hip -o /tmp/ac_fft_dbg.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/tools/libac_dbg_checks.so $OBJS /tmp/ac_fft_dbg.o
-ls -la /root/repo/tools/libac_dbg_checks.so
+/opt/rocm/bin/hipcc $FLAGS -c $T/applecider_amd/csrc/ac_fft.hip -o $T/ac_fft_dbg.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/libac_dbg_$V.so $OBJS $T/ac_fft_dbg.o
+rm -rf $T
+ls -la $R/tools/libac_dbg_$V.so
