@@ -770,7 +770,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ log
                                                    int kind, float gamma, float eps) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     float lb = 0.f;
-    if (b < B) {
+    if (b < B && kind == 3) {
+        // nn.MSELoss (mean over all B * C elements): SpectraNet's redshift regression (spectranet.py:178-179)
+        const float *t = (const float *)target + (int64_t)b * C;
+        const float inv = 1.0f / ((float)B * (float)C);
+        for (int c = 0; c < C; ++c) {
+            const float d = logits[(int64_t)b * C + c] - t[c];
+            lb += d * d * inv;
+            dlogits[(int64_t)b * C + c] = 2.f * d * inv;
+        }
+    } else if (b < B) {
         float z[LOSS_MAXC], y[LOSS_MAXC];
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) {
@@ -1099,7 +1108,7 @@ extern "C" int ac_loss_fwd_bwd(const float *logits, const void *target, const fl
                                float gamma, float eps, ac_stream_t stream) {
     if (!logits || !target || !loss || !dlogits || B <= 0 || C <= 0 || C > LOSS_MAXC)
         return AC_EINVAL;
-    if (kind < 0 || kind > 2) return AC_EINVAL;
+    if (kind < 0 || kind > 3) return AC_EINVAL;
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return -(int)e - 2000;
     hipLaunchKernelGGL(loss_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,

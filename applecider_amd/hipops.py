@@ -2459,8 +2459,10 @@ class _Loss(Function):
     def forward(ctx, logits, target, kind, gamma, eps, alpha):
         logits = _chk(logits, "logits")
         B, Cn = logits.shape
-        if kind == 0:
+        if kind in (0, 3):
             target = _chk(target, "target")
+            if tuple(target.shape) != tuple(logits.shape):
+                raise ValueError(f"loss target shape {tuple(target.shape)} != prediction shape {tuple(logits.shape)}")
         else:
             if target.dtype != torch.int64:
                 target = target.to(torch.int64)
@@ -2495,6 +2497,13 @@ def cross_entropy_index(logits, target_idx):
 
 def focal_loss(logits, target_idx, gamma=2.0, alpha=None, eps=0.0):
     return _Loss.apply(logits, target_idx, 2, float(gamma), float(eps), alpha)
+
+
+def mse_loss(pred, target):
+    """nn.MSELoss() (mean): pred / target [B] or [B, C] float (SpectraNet's redshift head, spectranet.py:178-179)."""
+    if pred.dim() == 1:
+        return _Loss.apply(pred.reshape(-1, 1), target.reshape(-1, 1).to(torch.float32), 3, 0.0, 0.0, None)
+    return _Loss.apply(pred, target.to(torch.float32), 3, 0.0, 0.0, None)
 
 
 # --------------------------------------------------------------------------- optimizer kernels

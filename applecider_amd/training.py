@@ -23,9 +23,18 @@ class CrossEntropyLoss:
         return H.cross_entropy_index(logits, target)
 
 
+class MSELoss:
+    """torch.nn.MSELoss() (mean reduction): the criterion of SpectraNet's `redshift = True` configuration, whose
+    train_step hands (outputs [B], redshifts [B]) to `self.criterion` (spectranet.py:178-179)."""
+
+    def __call__(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return H.mse_loss(pred, target)
+
+
 def attach_defaults(model, lr: float = 0.01, momentum: float = 0.9, weight_decay: float = 0.0):
     """Give `model` the optimizer / criterion pair Hyrax's defaults inject: SGD(lr, momentum) over the
-    flat parameter buffer (one streaming kernel per step) and CrossEntropyLoss.  Returns the model."""
+    flat parameter buffer (one streaming kernel per step) and CrossEntropyLoss — MSELoss when the model is a
+    regressor (`model.redshift`).  Returns the model."""
     model.optimizer = FlatSGD(model.parameters(), lr=lr, momentum=momentum, weight_decay=weight_decay)
-    model.criterion = CrossEntropyLoss()
+    model.criterion = MSELoss() if getattr(model, "redshift", False) else CrossEntropyLoss()
     return model

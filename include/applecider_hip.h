@@ -500,6 +500,8 @@ int ac_softmax_fwd(const float *x, float *y, int64_t rows, int32_t C, ac_stream_
  *   kind 0: CrossEntropyLoss with class-probability targets  (astrominn.py:147,315)
  *   kind 1: CrossEntropyLoss with int64 class indices         (brew_cider.py:1229)
  *   kind 2: FocalLoss(gamma, alpha, eps)                      (HyraxBaselineCLS.py:169-191)
+ *   kind 3: MSELoss, float targets [B, C], mean over B * C    (SpectraNet redshift regression, spectranet.py:178-179;
+ *           "logits" are the predictions)
  * loss is a single device float, zeroed by the call.
  * ---------------------------------------------------------------------- */
 int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha, float *loss,

@@ -169,8 +169,9 @@ def encoder_layer(sd, p, x, key_pad, n_heads):
 
 
 def baselinecls_forward(sd, data, pad, n_heads=8, n_layers=4, classification=True,
-                        use_probabilities=False):
-    """HyraxBaselineCLS.forward (HyraxBaselineCLS.py:49-86)."""
+                        use_probabilities=False, out_key="fc"):
+    """HyraxBaselineCLS.forward (HyraxBaselineCLS.py:49-86).  out_key = "head": the legacy non-Hyrax `BaselineCLS`
+    (Time2Vec.py:80-124), which is the same network classified through `head` instead of `fc`."""
     B = data.shape[0]
     h = _lin(sd, "in_proj", data) + time2vec(sd, "time2vec", data[..., 0])
     h = torch.cat([sd["cls_tok"].expand(B, -1, -1), h], 1)
@@ -179,10 +180,27 @@ def baselinecls_forward(sd, data, pad, n_heads=8, n_layers=4, classification=Tru
         h = encoder_layer(sd, f"encoder.layers.{i}", h, pad_ext, n_heads)
     out = _ln(sd, "norm", h[:, 0])
     if classification:
-        out = _lin(sd, "fc", out)
+        out = _lin(sd, out_key, out)
     if use_probabilities:
         out = F.softmax(out, 1)
     return out
+
+
+def mpt_heads(sd, z):
+    """Legacy MPTModel(base_enc).forward (Time2Vec.py:128-142): the three heads over an encoder output."""
+    return _lin(sd, "head_flux", z), _lin(sd, "head_band", z), _lin(sd, "head_dt", z)
+
+
+def pretrained_handoff(own_sd, checkpoint_sd):
+    """`self.load_state_dict(torch.load(path), strict=False)` (HyraxBaselineCLS.py:43-47) on state_dicts: every key
+    of the model that the checkpoint also holds takes the checkpoint's value, the others keep the model's own; keys
+    only the checkpoint holds (an MPTModel's head_flux / head_band / head_dt) are ignored.
+    Returns (merged, taken keys, kept keys, ignored keys)."""
+    taken = sorted(k for k in own_sd if k in checkpoint_sd)
+    kept = sorted(k for k in own_sd if k not in checkpoint_sd)
+    ignored = sorted(k for k in checkpoint_sd if k not in own_sd)
+    merged = {k: (checkpoint_sd[k] if k in checkpoint_sd else own_sd[k]) for k in own_sd}
+    return merged, taken, kept, ignored
 
 
 def mpt_apply_mask(data, masked):
@@ -272,17 +290,23 @@ def spectranet_forward(sd, x, kernel_sizes_per_stage, depths=None, head="classif
     return (out, stages) if return_stages else out
 
 
-def spectranet_train_steps(sd, flux, labels, kernel_sizes_per_stage, n_steps=1, lr=0.01, momentum=0.9):
+def spectranet_train_steps(sd, flux, labels, kernel_sizes_per_stage, n_steps=1, lr=0.01, momentum=0.9,
+                           redshifts=None):
     """SpectraNet.train_step (spectranet.py:172-184) under the optimizer / criterion Hyrax injects
     (torch.optim.SGD(lr, momentum), CrossEntropyLoss; spectranet_testing.ipynb cell 14), restated on a
     state_dict: zero_grad -> forward -> CE -> backward -> buf = momentum*buf + g ; p -= lr*buf
     (torch.optim.SGD: the first step initialises buf = g).  Labels may be any integer dtype (the
-    reference's to_tensor emits int16, spectranet.py:204).  Returns (losses, updated state_dict)."""
+    reference's to_tensor emits int16, spectranet.py:204).  `redshifts` given = the `redshift = True` model
+    (spectranet.py:139-147,167-168,178-179): regressor head, squeezed, MSELoss against the redshifts.
+    Returns (losses, updated state_dict)."""
     sd = {k: v.detach().clone().requires_grad_() for k, v in sd.items()}
     buf, losses = {}, []
     for _ in range(n_steps):
-        logits = spectranet_forward(sd, flux, kernel_sizes_per_stage)
-        loss = F.cross_entropy(logits, labels.long())
+        if redshifts is not None:
+            loss = F.mse_loss(spectranet_forward(sd, flux, kernel_sizes_per_stage, head="regressor"), redshifts)
+        else:
+            logits = spectranet_forward(sd, flux, kernel_sizes_per_stage)
+            loss = F.cross_entropy(logits, labels.long())
         grads = torch.autograd.grad(loss, list(sd.values()))
         losses.append(float(loss.detach()))
         with torch.no_grad():

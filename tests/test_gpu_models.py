@@ -485,3 +485,169 @@ def test_mpt_train_step_runs_with_dropout(dev):
     l0 = m.train_step((T(b["photometry"]).to(dev), T(b["pad_mask"]).to(dev), None))["loss"]
     l1 = m.train_step((T(b["photometry"]).to(dev), T(b["pad_mask"]).to(dev), None))["loss"]
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+# ----------------------------------------------------------------------------- round 4: F1 / f-4 pins on the GPU
+class _GivenEmbedding(torch.nn.Module):
+    """Stub encoder of the g13 fixture: returns the embedding it was given, whatever it is called with."""
+
+    def __init__(self, value):
+        super().__init__()
+        self.value = value
+
+    def forward(self, *a, **kw):
+        return self.value
+
+
+@pytest.mark.parametrize("streams", [False, True])
+@pytest.mark.parametrize("fusion", ["avg", "concat"])
+def test_fusion_head_golden_vs_archive_class(dev, gmode, fusion, streams):
+    """F1 against the archive's own class (golden g13 = `class AppleCider` of brew_cider.py:807-862 executed from its
+    text with stub encoders): the product's projections, L2 normalisation, avg | concat and fc, CE loss, gradients of
+    the head's parameters and of the three encoder outputs — on one stream and with the three encoder streams."""
+    import copy
+    from applecider_amd import hipops as H
+    from applecider_amd.models.applecider import AppleCider
+    from test_oracle_golden import fusion_sd
+    g = gold("g13_fusion.npz")
+    mc = copy.deepcopy(cfg_default())
+    mc["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    mc["model"]["SpectraNet"]["class_order"] = 256      # the archive's spectra encoder emits 256 features (:827)
+    fc = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 1, "p_dropout": 0.0, "max_len": 257,
+          "num_classes": 5, "hidden_dim": 64, "fusion": fusion, "lr": 1e-3, "model_config": mc}
+    m = AppleCider(fc)
+    m.load_state_dict(fusion_sd(fusion), strict=False)
+    m = m.to(dev).eval()
+    m.branch_streams = streams
+    emb = {k: T(g[f"in.{k}_emb"]).to(dev).requires_grad_() for k in ("p", "s", "im")}
+    m.photometry_encoder = _GivenEmbedding(emb["p"])
+    m.spectra_encoder = _GivenEmbedding(emb["s"])
+    m.img_metadata_encoder = _GivenEmbedding(emb["im"])
+    dummy = torch.zeros(1, device=dev)
+    p_e, im_e, s_e = m.get_embeddings(dummy, dummy, dummy, dummy, dummy)
+    for key, t in (("p", p_e), ("im", im_e), ("s", s_e)):
+        assert_close(t, g[f"{fusion}.{key}_unit"], LOGIT_TOL, key + "_unit", x3=1e-4)
+    logits = m(dummy, dummy, dummy, dummy, dummy)
+    assert_close(logits, g[f"{fusion}.logits"], LOGIT_TOL, "logits", x3=1e-4)
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g[f"{fusion}.logits"].argmax(1))
+    loss = H.cross_entropy_index(logits, T(g["in.labels"]).to(dev))
+    assert_close(loss, g[f"{fusion}.loss"], LOGIT_TOL, "loss", x3=1e-4)
+    m.optimizer.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    gr = grads_by_ref_name(m)
+    n = 0
+    for k in g.files:
+        if not k.startswith(f"{fusion}.grad."):
+            continue
+        name = k[len(fusion) + 6:]
+        got = emb[name[:-4]].grad if name.endswith("_emb") else gr[name]
+        assert_close(got, g[k], GRAD_TOL, "grad " + name)
+        n += 1
+    assert n == 11
+
+
+def test_spectranet_redshift_golden(dev, gmode):
+    """SpectraNet's `redshift = True` path (spectranet.py:139-147,167-168,178-179; golden g14 = the reference run as a
+    regressor): prediction [B], MSELoss, gradients, then two train_steps under SGD(0.01, 0.9) + MSELoss."""
+    from applecider_amd import hipops as H
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.training import MSELoss, attach_defaults
+    from test_oracle_golden import _g14_setup
+    g, cfg, flux, label, z = _g14_setup()
+    m = build(SpectraNet, cfg, dev).eval()
+    batch = (T(flux).to(dev), T(label).to(dev), T(z).to(dev))
+    y = m(batch)
+    assert tuple(y.shape) == (4,)
+    assert_close(y, g["pred"], LOGIT_TOL, "pred")
+    loss = H.mse_loss(y, batch[2])
+    assert_close(loss, g["mse"], LOGIT_TOL, "mse")
+    loss.backward()
+    gr = grads_by_ref_name(m)
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+    m = attach_defaults(build(SpectraNet, cfg, dev).eval())
+    assert isinstance(m.criterion, MSELoss)
+    l1 = m.train_step(batch)["loss"]
+    l2 = m.train_step(batch)["loss"]
+    assert abs(l1 - float(g["loss1"])) <= LOGIT_TOL * abs(float(g["loss1"]))
+    assert abs(l2 - float(g["loss2"])) <= 3e-3 * abs(float(g["loss2"]))
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("after_step2."):
+            assert_close(compact(sd[k[12:]].detach().cpu().numpy()), g[k], 1e-3, k)
+    with torch.no_grad():
+        assert_close(m(batch), g["pred_after_step2"], 5e-3, "pred after two SGD steps")
+
+
+@pytest.mark.parametrize("mode", ["photo", "all"])
+def test_pretrain_handoff_golden(dev, gmode, mode, tmp_path):
+    """Pre-train -> fine-tune hand-off on the GPU path (HyraxBaselineCLS.py:43-47; golden g15): an MPTModel that lived
+    on the device saves its state_dict (reference key names and layouts), HyraxBaselineCLS(pretrained_weights_path_=)
+    loads it with strict=False, and the classifier's outputs are the reference's."""
+    import copy
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS, MPTModel
+    from test_oracle_golden import _g15_inputs
+    g = gold("g15_pretrain_handoff.npz")
+    cfg = cfg_default()
+    cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0, "mode": mode})
+    mpt = build(MPTModel, cfg, dev, salt=15)
+    path = str(tmp_path / "mpt.pt")
+    torch.save(mpt.state_dict(), path)
+    ck = torch.load(path, map_location="cpu")
+    assert sorted(k for k in ck if k.startswith("head_")) == list(g["ignored"])
+    own = closed_form_sd(HyraxBaselineCLS(cfg))
+    c2 = copy.deepcopy(cfg)
+    c2["model"]["HyraxBaselineCLS"]["pretrained_weights_path_"] = path
+    m = HyraxBaselineCLS(c2)
+    sd = m.state_dict()
+    assert sorted(k for k in sd if k in ck) == list(g[f"{mode}.taken"])
+    kept = [k for k in sd if k not in ck]
+    assert sorted(kept) == list(g[f"{mode}.kept"])
+    m.load_state_dict({**sd, **{k: own[k] for k in kept}})
+    m = m.to(dev).eval()
+    data, pad = _g15_inputs()
+    with torch.no_grad():
+        y = m((T(data).to(dev), T(pad).to(dev), None))
+    assert_close(y, g[f"{mode}.out"], LOGIT_TOL, "output after hand-off")
+    if mode == "photo":
+        assert np.array_equal(y.argmax(1).cpu().numpy(), g[f"{mode}.out"].argmax(1))
+
+
+def test_legacy_ctors_golden(dev, gmode):
+    """The non-Hyrax constructors of Time2Vec.py:80-142 on the GPU path (golden g16): BaselineCLS(d_model, n_heads,
+    n_layers, num_classes, dropout, max_len) forward (eval + train paths) and gradients; MPTModel(base_enc) shares the
+    encoder and applies its three heads."""
+    from applecider_amd.models.Time2Vec import BaselineCLS, MPTModel
+    from test_oracle_golden import _g16_inputs
+    g = gold("g16_legacy_ctors.npz")
+    enc = BaselineCLS(128, 8, 4, 5, 0.0, max_len=257)
+    enc.load_state_dict(closed_form_sd(enc))
+    enc = enc.to(dev)
+    data, pad = _g16_inputs()
+    x, pm = T(data).to(dev), T(pad).to(dev)
+    enc.eval()
+    with torch.no_grad():
+        assert_close(enc(x, pm), g["cls.eval"], LOGIT_TOL, "eval")
+    enc.train()
+    y = enc(x, pm)
+    assert_close(y, g["cls.train"], LOGIT_TOL, "train")
+    y.backward(2.0 * y.detach())
+    gr = grads_by_ref_name(enc)
+    for k in g.files:
+        if k.startswith("cls.grad."):
+            assert_close(compact(gr[k[9:]].detach().cpu().numpy()), g[k], GRAD_TOL, k, x3=5e-3)
+    mpt = MPTModel(enc)
+    assert mpt.encoder is enc.encoder
+    msd = closed_form_sd(mpt)
+    mpt.load_state_dict(msd)
+    mpt = mpt.to(dev)
+    z = T(np.random.default_rng(16).standard_normal((4, 129, 128)).astype(np.float32)).to(dev).requires_grad_()
+    f, bnd, dt = mpt(z)
+    assert_close(f, g["mpt.flux"], LOGIT_TOL, "flux")
+    assert_close(bnd, g["mpt.band"], LOGIT_TOL, "band")
+    assert_close(dt, g["mpt.dt"], LOGIT_TOL, "dt")
+    torch.autograd.backward([f, bnd, dt], [2.0 * f.detach(), 2.0 * bnd.detach(), 2.0 * dt.detach()])
+    assert_close(compact(z.grad.cpu().numpy()), g["mpt.dz"], GRAD_TOL, "dz")
+    assert_close(grads_by_ref_name(mpt)["head_band.weight"], g["mpt.grad.head_band.weight"], GRAD_TOL, "d head_band")

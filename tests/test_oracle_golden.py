@@ -426,3 +426,173 @@ def test_split_and_tile_planners():
         tile, split = H._tn_plan(m, n, k)
         assert tile == 4 and (k // 64) // split >= 64
         assert (-(-m // 128) * -(-n // 256) * split) <= 1024
+
+
+# ----------------------------------------------------------------------------- round 4: F1 / f-4 pins
+FUSION_SHAPES = {"photometry_proj.weight": (64, 128), "photometry_proj.bias": (64,),
+                 "spectra_proj.weight": (64, 256), "spectra_proj.bias": (64,),
+                 "img_metadata_proj.weight": (64, 5), "img_metadata_proj.bias": (64,)}
+
+
+def fusion_sd(fusion):
+    from oracle.weights import closed_form_state_dict
+    shapes = dict(FUSION_SHAPES)
+    shapes["fc.weight"], shapes["fc.bias"] = (5, 192 if fusion == "concat" else 64), (5,)
+    return closed_form_state_dict(shapes)
+
+
+@pytest.mark.parametrize("fusion", ["avg", "concat"])
+def test_g13_fusion_head_oracle_vs_archive_class(fusion):
+    """F1 pinned (VERDICT r3 missing #1): oracle.fusion_head against the archive's own `class AppleCider`
+    (_archive/notebooks/brew_cider.py:807-862, executed from its text with stub encoders by tools/make_goldens.py
+    g13_fusion): unit embeddings, logits, CE loss and every gradient of the head."""
+    from oracle import functional as O
+    g = gold("g13_fusion.npz")
+    assert tuple(g["source_lines"]) == (807, 866)      # the class statement the fixture came from (start, first line after it)
+    sd = {k: v.requires_grad_() for k, v in fusion_sd(fusion).items()}
+    emb = {k: T(g[f"in.{k}_emb"]).requires_grad_() for k in ("p", "s", "im")}
+    logits = O.fusion_head(sd, emb["p"], emb["s"], emb["im"], fusion)
+    assert_close(logits, g[f"{fusion}.logits"], TOL, "logits")
+    assert np.array_equal(logits.argmax(1).numpy(), g[f"{fusion}.logits"].argmax(1))
+    loss = F.cross_entropy(logits, T(g["in.labels"]))
+    assert_close(loss, g[f"{fusion}.loss"], TOL, "loss")
+    loss.backward()
+    for k in g.files:
+        if k.startswith(f"{fusion}.grad."):
+            name = k[len(fusion) + 6:]
+            got = emb[name[:-4]].grad if name.endswith("_emb") else sd[name].grad
+            assert_close(got, g[k], 5e-5, k)
+    # the normalised embeddings themselves
+    for key, unit in (("p", "photometry_proj"), ("im", "img_metadata_proj"), ("s", "spectra_proj")):
+        u = O._lin(sd, unit, emb[key])
+        assert_close(u / u.norm(dim=-1, keepdim=True), g[f"{fusion}.{key}_unit"], TOL, key + "_unit")
+
+
+def _g14_setup():
+    from applecider_amd.models.spectranet import SpectraNet
+    from applecider_amd.synthetic import make_batch
+    g = gold("g14_spectranet_redshift.npz")
+    cfg = cfg_default()
+    cfg["model"]["SpectraNet"].update(SMALL_SPECTRA)
+    cfg["model"]["SpectraNet"]["redshift"] = True
+    b = make_batch(4, seed=14, spec_len=256)
+    flux, label, z = SpectraNet.to_tensor({"data": {"flux": b["spectra"], "label": b["label"], "redshift": g["in.redshift"]}})
+    return g, cfg, flux, label, z
+
+
+def test_g14_spectranet_redshift_oracle():
+    """SpectraNet's regressor path (spectranet.py:139-147,167-168,178-179; VERDICT r3 missing #2): prediction, MSE,
+    gradients and two SGD steps against the reference run with `redshift = True`."""
+    from applecider_amd.models.spectranet import SpectraNet
+    from oracle import functional as O
+    g, cfg, flux, label, z = _g14_setup()
+    ks = cfg["model"]["SpectraNet"]["kernel_sizes_per_stage"]
+    model = SpectraNet(cfg)
+    assert hasattr(model, "regressor") and not hasattr(model, "classifier")
+    sd0 = closed_form_sd(model)
+    sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+    y = O.spectranet_forward(sd, T(flux), ks, head="regressor")
+    assert y.shape == (4,)
+    assert_close(y, g["pred"], TOL, "pred")
+    loss = F.mse_loss(y, T(z))
+    assert_close(loss, g["mse"], 5e-5, "mse")
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad."):
+            assert_close(compact(sd[k[5:]].grad.numpy()), g[k], 2e-4, k)
+    losses, sd2 = O.spectranet_train_steps(sd0, T(flux), None, ks, n_steps=2, redshifts=T(z))
+    assert abs(losses[0] - float(g["loss1"])) <= 5e-5 * abs(float(g["loss1"]))
+    assert abs(losses[1] - float(g["loss2"])) <= 1e-4 * abs(float(g["loss2"]))
+    for k in g.files:
+        if k.startswith("after_step2."):
+            assert_close(compact(sd2[k[12:]].numpy()), g[k], 5e-5, k)
+    with torch.no_grad():
+        assert_close(O.spectranet_forward(sd2, T(flux), ks, head="regressor"), g["pred_after_step2"], 5e-4, "pred after 2 steps")
+
+
+def _g15_inputs():
+    from applecider_amd.synthetic import make_batch
+    L = 128
+    b = make_batch(4, seed=15, L=L)
+    pad = np.arange(L)[None, :] >= np.array([L, 64, 9, 30])[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    return data, pad
+
+
+@pytest.mark.parametrize("mode", ["photo", "all"])
+def test_g15_pretrain_handoff_oracle_and_product_loader(mode, tmp_path):
+    """Pre-train -> fine-tune hand-off (HyraxBaselineCLS.py:43-47; VERDICT r3 missing #4): the PRODUCT's MPTModel
+    state_dict (reference key names, salt-15 weights) is saved with torch.save and loaded by the PRODUCT's
+    HyraxBaselineCLS(pretrained_weights_path_=...) on CPU: the keys taken / kept / ignored are the reference's, and
+    the merged weights give the reference's outputs through the oracle."""
+    from applecider_amd.models.HyraxBaselineCLS import HyraxBaselineCLS, MPTModel
+    from oracle import functional as O
+    g = gold("g15_pretrain_handoff.npz")
+    cfg = cfg_default()
+    cfg["model"]["HyraxBaselineCLS"].update({"dropout": 0.0, "mode": mode})
+    mpt = MPTModel(cfg)
+    ck = closed_form_sd(mpt, salt=15)
+    mpt.load_state_dict(ck)
+    path = str(tmp_path / "mpt.pt")
+    torch.save(mpt.state_dict(), path)
+    own = closed_form_sd(HyraxBaselineCLS(cfg))
+    merged, taken, kept, ignored = O.pretrained_handoff(own, ck)
+    assert taken == list(g[f"{mode}.taken"]) and kept == list(g[f"{mode}.kept"]) and ignored == list(g["ignored"])
+    data, pad = _g15_inputs()
+    with torch.no_grad():
+        y = O.baselinecls_forward(merged, T(data), T(pad), classification=(mode == "photo"))
+    assert_close(y, g[f"{mode}.out"], 5e-5, "output after hand-off")
+    # the product's constructor path: same keys end up with the checkpoint's values
+    c2 = copy.deepcopy(cfg)
+    c2["model"]["HyraxBaselineCLS"]["pretrained_weights_path_"] = path
+    m = HyraxBaselineCLS(c2)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(own.keys())
+    for k in taken:
+        assert torch.equal(sd[k], ck[k]), k
+    m.load_state_dict({**sd, **{k: own[k] for k in kept}})
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, merged[k]), k
+
+
+def _g16_inputs():
+    from applecider_amd.synthetic import make_batch
+    L = 128
+    b = make_batch(4, seed=16, L=L)
+    pad = np.arange(L)[None, :] >= np.array([L, 50, 3, 77])[:, None]
+    data = b["photometry"].copy()
+    data[pad] = 0.0
+    return data, pad
+
+
+def test_g16_legacy_ctors_oracle():
+    """The non-Hyrax constructors (Time2Vec.py:80-142; VERDICT r3 missing #5): BaselineCLS(d_model, n_heads, n_layers,
+    num_classes, dropout, max_len) classifies through `head`; MPTModel(base_enc) shares the encoder and applies
+    three heads."""
+    from applecider_amd.models.Time2Vec import BaselineCLS, MPTModel
+    from oracle import functional as O
+    g = gold("g16_legacy_ctors.npz")
+    enc = BaselineCLS(128, 8, 4, 5, 0.0, max_len=257)
+    mpt = MPTModel(enc)
+    assert mpt.encoder is enc.encoder
+    assert sorted(mpt.state_dict().keys()) == list(g["mpt.state_dict_keys"])
+    data, pad = _g16_inputs()
+    sd = {k: v.requires_grad_() for k, v in closed_form_sd(enc).items()}
+    y = O.baselinecls_forward(sd, T(data), T(pad), out_key="head")
+    assert_close(y, g["cls.train"], 5e-5, "train path")
+    assert_close(y, g["cls.eval"], 5e-5, "eval path")
+    y.square().sum().backward()
+    for k in g.files:
+        if k.startswith("cls.grad."):
+            assert_close(compact(sd[k[9:]].grad.numpy()), g[k], 3e-4, k)
+    msd = {k: v.requires_grad_() for k, v in closed_form_sd(mpt).items()}
+    z = T(np.random.default_rng(16).standard_normal((4, 129, 128)).astype(np.float32)).requires_grad_()
+    assert_close(compact(z.detach().numpy()), g["in.z"], 0, "z")
+    f, bnd, dt = O.mpt_heads(msd, z)
+    assert_close(f, g["mpt.flux"], TOL, "flux")
+    assert_close(bnd, g["mpt.band"], TOL, "band")
+    assert_close(dt, g["mpt.dt"], TOL, "dt")
+    (f.square().sum() + bnd.square().sum() + dt.square().sum()).backward()
+    assert_close(compact(z.grad.numpy()), g["mpt.dz"], 5e-5, "dz")
+    assert_close(msd["head_band.weight"].grad, g["mpt.grad.head_band.weight"], 5e-5, "d head_band")
