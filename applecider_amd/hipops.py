@@ -710,6 +710,8 @@ class _Linear(Function):
                 gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
                      pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
                      drop_p=ctx.drop_p, drop_seed=ctx.drop_seed)
+        if act == ACT_RELU and ROUTING_TAP is not None:
+            _tap("relu", pre if pre is not None else y)     # (sign pattern = the gates; tests: ROUTING_TAP)
         ctx.act, ctx.has_res = act, residual is not None
         ctx.shape_x = x.shape
         ctx.has_b = b is not None
@@ -1571,6 +1573,17 @@ def avgpool_tokens(x):
 
 
 # --------------------------------------------------------------------------- spectra branch
+# Tests: a list here receives ("pool4" | "global", index tensor) from every max-pool forward, in call order — the
+# routing a gradient comparison needs (max-pooling makes the gradient discontinuous at near-tie windows; the oracle can
+# be evaluated under THIS routing: oracle.functional.spectranet_forward(routing=)).  None = off.
+ROUTING_TAP = None
+
+
+def _tap(kind, idx):
+    if ROUTING_TAP is not None:
+        ROUTING_TAP.append((kind, idx))
+
+
 class _MaxPool4(Function):
     @staticmethod
     def forward(ctx, x):
@@ -1581,6 +1594,7 @@ class _MaxPool4(Function):
         idx = torch.empty(B, Lo, Cn, device=x.device, dtype=torch.uint8)
         _lib.check(_lib_().ac_maxpool4_fwd(_p(x), _p(y), Lo * Cn, _p(idx), B, L, Cn, _stream()),
                    "ac_maxpool4_fwd")
+        _tap("pool4", idx)
         ctx.save_for_backward(idx)
         ctx.shape = (B, L, Cn)
         return y
@@ -1609,6 +1623,7 @@ class _GlobalMax(Function):
         idx = torch.empty(B, Cn, device=x.device, dtype=torch.int32)
         _lib.check(_lib_().ac_globalmax_fwd(_p(x), _p(y), _p(idx), B, L, Cn, _stream()),
                    "ac_globalmax_fwd")
+        _tap("global", idx)
         ctx.save_for_backward(idx)
         ctx.shape = (B, L, Cn)
         return y
@@ -2041,6 +2056,7 @@ class _ConvGroup1d(Function):
             _lib.check(_lib_().ac_ln_gelu_pw_pool_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), ln_eps, _p(pw_w),
                                                       _p(pw_b), _p(z), _p(mean), _p(rstd), _p(pooled), _p(pidx), rows,
                                                       Ncat, Cpw, _stream()), "ac_ln_gelu_pw_pool_fwd")
+            _tap("pool4", pidx)
             ctx.tail, ctx.pw = True, (pw_w, pw_b)
             ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta, z, pidx, pw_w)
             return pooled

@@ -19,6 +19,26 @@ def _lin(sd, p, x):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
+# Tests only (the ReLU counterpart of spectranet_forward's `routing`): ReLU' is discontinuous at 0, so a unit whose
+# pre-activation is within two implementations' rounding of zero may be open in one and closed in the other, and its
+# whole upstream gradient row differs by one token's contribution.  RELU_GATES = {site: [bool masks in call order]}
+# makes the ReLUs of that site use THOSE gates (y = x * gate); every call is recorded under "_seen"[site] as
+# (own gate, |x| / max |x|) so that a test can show the differing gates were all near zero.  None = plain F.relu.
+RELU_GATES = None
+
+
+def _relu(x, site):
+    if RELU_GATES is None:
+        return F.relu(x)
+    seen = RELU_GATES.setdefault("_seen", {}).setdefault(site, [])
+    xd = x.detach()
+    seen.append((xd > 0, xd.abs() / xd.abs().max().clamp_min(1e-30)))
+    given = RELU_GATES.get(site)
+    if given is None:
+        return F.relu(x)
+    return x * given[len(seen) - 1].reshape(x.shape).to(x.dtype)
+
+
 def _ln(sd, p, x, eps=1e-5):
     w = sd[p + ".weight"]
     return F.layer_norm(x, (w.numel(),), w, sd[p + ".bias"], eps)
@@ -97,7 +117,7 @@ def split_head_convnext(sd, p, x, features=None):
     """SplitHeadConvNeXt.forward (astrominn.py:8-41): main(f) * aux(f)."""
     f = convnext_tiny_features(sd, p + ".backbone", x) if features is None else features
     m = _ln(sd, p + ".head_main.1", F.gelu(f))
-    m = F.relu(_lin(sd, p + ".head_main.2", m))
+    m = _relu(_lin(sd, p + ".head_main.2", m), "image_head")
     m = _lin(sd, p + ".head_main.6", _lin(sd, p + ".head_main.5", m))
     a = torch.tanh(_lin(sd, p + ".head_aux.1", _ln(sd, p + ".head_aux.0", f)))
     return m * a
@@ -164,7 +184,7 @@ def encoder_layer(sd, p, x, key_pad, n_heads):
     s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
     a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, D)
     x = _ln(sd, p + ".norm1", x + _lin(sd, p + ".self_attn.out_proj", a))
-    ff = _lin(sd, p + ".linear2", F.relu(_lin(sd, p + ".linear1", x)))
+    ff = _lin(sd, p + ".linear2", _relu(_lin(sd, p + ".linear1", x), "encoder_ff"))
     return _ln(sd, p + ".norm2", x + ff)
 
 
@@ -252,7 +272,7 @@ def focal_loss(logits, target, gamma=2.0, alpha=None, eps=0.0):
 
 
 # ----------------------------------------------------------------------------- C1, C2: SpectraNet
-def spectranet_block(sd, p, x, ksizes, do_pool, use_ln=True, training=False):
+def spectranet_block(sd, p, x, ksizes, do_pool, use_ln=True, training=False, routing=None):
     """SpectraNetBlock.forward (spectranet.py:28-41); x is [B,C,L].  use_ln=False: nn.BatchNorm1d over
     the channels (spectranet.py:21,33) — batch statistics and in-place running-statistics update when
     `training`, running statistics otherwise."""
@@ -265,13 +285,54 @@ def spectranet_block(sd, p, x, ksizes, do_pool, use_ln=True, training=False):
                                 sd[p + ".norm.weight"], sd[p + ".norm.bias"], training, 0.1, 1e-5))
     if do_pool:
         y = F.conv1d(y, sd[p + ".downsample.weight"], sd[p + ".downsample.bias"])
-        y = F.max_pool1d(y, 4)
+        y = _pool4(y, routing)
     return y
 
 
+def _pool4(y, routing):
+    """MaxPool1d(4) (spectranet.py:40).  `routing` (tests only, see spectranet_forward): records this pool's window
+    margins and, when it carries indices, selects THOSE positions instead of the arg-max."""
+    if routing is None:
+        return F.max_pool1d(y, 4)
+    B, C, L = y.shape
+    w = y.reshape(B, C, L // 4, 4)
+    top = w.detach().topk(2, dim=-1)
+    routing.setdefault("margins", []).append((top.values[..., 0] - top.values[..., 1]) / w.detach().abs().max())
+    # the position torch's own max_pool1d routes to (first maximum on exact ties - e.g. the constant rows behind an
+    # all-zero spectrum), as window positions 0..3
+    own = F.max_pool1d(y.detach(), 4, return_indices=True)[1] - 4 * torch.arange(L // 4).view(1, 1, -1)
+    routing.setdefault("argmax", []).append(own)
+    given = routing.get("pool")
+    if given is None:
+        return w.max(-1).values
+    idx = given[len(routing["argmax"]) - 1].long()
+    return w.gather(-1, idx.unsqueeze(-1)).squeeze(-1)
+
+
+def _global_max(x, routing):
+    """adaptive_max_pool1d(., 1) (spectranet.py:161) with the same routing hook as _pool4."""
+    if routing is None:
+        return F.adaptive_max_pool1d(x, 1).squeeze(-1)
+    if x.shape[-1] < 2:
+        routing["global_margin"] = torch.full(x.shape[:-1], float("inf"))
+        routing["global_argmax"] = torch.zeros(x.shape[:-1], dtype=torch.long)
+    else:
+        top = x.detach().topk(2, dim=-1)
+        routing["global_margin"] = (top.values[..., 0] - top.values[..., 1]) / x.detach().abs().max()
+        routing["global_argmax"] = F.adaptive_max_pool1d(x.detach(), 1, return_indices=True)[1].squeeze(-1)
+    if routing.get("global") is None:
+        return x.max(-1).values
+    return x.gather(-1, routing["global"].long().unsqueeze(-1)).squeeze(-1)
+
+
 def spectranet_forward(sd, x, kernel_sizes_per_stage, depths=None, head="classifier",
-                       return_stages=False, use_ln_stages=None, training=False):
-    """SpectraNet.forward (spectranet.py:157-170); x is [B,1,L]."""
+                       return_stages=False, use_ln_stages=None, training=False, routing=None):
+    """SpectraNet.forward (spectranet.py:157-170); x is [B,1,L].
+    `routing` (a dict, tests only): the max-pools record their windows' top-2 margins (relative to the tensor's
+    max-abs) and arg-max positions into it; if it holds "pool" (list of [B, C, L/4] window positions 0..3, one per
+    pooled stage) / "global" ([B, C] positions), the pools select THOSE positions — the gradient of the reference's
+    network under another implementation's routing of near-tie windows, which is how a GPU gradient is compared
+    tightly although max-pooling makes the gradient discontinuous."""
     n = len(kernel_sizes_per_stage)
     depths = depths or [1] * n
     use_ln_stages = use_ln_stages or [True] * n
@@ -280,9 +341,9 @@ def spectranet_forward(sd, x, kernel_sizes_per_stage, depths=None, head="classif
         for j in range(depths[i]):
             x = spectranet_block(sd, f"all_stages.{i}.{j}", x, kernel_sizes_per_stage[i],
                                  do_pool=(i < n - 1 and j == depths[i] - 1), use_ln=use_ln_stages[i],
-                                 training=training)
+                                 training=training, routing=routing)
         stages.append(x)
-    z = F.adaptive_max_pool1d(x, 1).squeeze(-1)
+    z = _global_max(x, routing)
     z = F.gelu(_ln(sd, head + ".1", _lin(sd, head + ".0", z)))
     out = _lin(sd, head + ".4", z)
     if head == "regressor":
@@ -342,6 +403,7 @@ def applecider_forward(sd, photometry, photo_mask, metadata, images, spectra, cf
     SpectraNet logits, img_metadata_encoder = AstroMiNN logits."""
     p_emb = baselinecls_forward(_sub(sd, "photometry_encoder."), photometry, photo_mask,
                                 cfg["p_n_heads"], cfg["p_n_layers"], classification=False)
-    s_emb = spectranet_forward(_sub(sd, "spectra_encoder."), spectra, cfg["kernel_sizes_per_stage"])
+    s_emb = spectranet_forward(_sub(sd, "spectra_encoder."), spectra, cfg["kernel_sizes_per_stage"],
+                               routing=cfg.get("routing"))
     im_emb = astrominn_forward(_sub(sd, "img_metadata_encoder."), metadata, images)
     return fusion_head(sd, p_emb, s_emb, im_emb, cfg["fusion"])

@@ -107,3 +107,81 @@ def grads_by_ref_name(module):
                 g = mod.to_reference(g)
             out[pre + pname] = g
     return out
+
+
+# ----------------------------------------------------------------------------- max-pool routing (gradient parity)
+class routing_tap:
+    """with routing_tap() as tap: ... product forward ...  -> tap.routing() = the oracle's `routing` argument holding
+    the positions the PRODUCT's max-pools selected.  MaxPool1d / adaptive_max_pool1d make the gradient discontinuous:
+    a window whose two largest values differ by less than the two implementations' rounding may send its gradient to
+    the other position.  Evaluating the oracle under the product's routing removes exactly that effect, so the
+    gradients can be held to the tight bound; `routing_mismatches` then bounds how many windows were routed differently
+    and shows that each of them was a near-tie."""
+
+    def __enter__(self):
+        from applecider_amd import hipops as H
+        self.H, self.items = H, []
+        H.ROUTING_TAP = self.items
+        return self
+
+    def __exit__(self, *exc):
+        self.H.ROUTING_TAP = None
+
+    def relu_gates(self):
+        """{oracle site: [gate masks in call order]} of the product's ReLUs: the encoder feed-forward (hidden width
+        4 * d_model = 512, one per layer) and the image head's Linear(768 -> 384) + ReLU (astrominn.py:27)."""
+        relus = [t.detach().cpu() > 0 for kind, t in self.items if kind == "relu"]
+        return {"encoder_ff": [t for t in relus if t.shape[-1] == 512],
+                "image_head": [t for t in relus if t.shape[-1] == 384]}
+
+    def routing(self):
+        pools = [idx.permute(0, 2, 1).cpu().long() for kind, idx in self.items if kind == "pool4"]
+        glob = [idx.cpu().long() for kind, idx in self.items if kind == "global"]
+        assert len(glob) == 1, "one SpectraNet forward per tap"
+        return {"pool": pools, "global": glob[0]}
+
+
+def routing_mismatches(routing, max_margin=1e-3, max_frac=2e-3):
+    """After an oracle forward under `routing`: number of windows the product routed differently from the oracle's own
+    arg-max, asserting every one of them is a near-tie (top-2 margin <= max_margin of the tensor's max-abs) and that
+    they are few (<= max_frac of the windows)."""
+    n_bad = n_all = n_tied = 0
+    worst = 0.0
+    pairs = list(zip(routing["pool"], routing["argmax"], routing["margins"]))
+    pairs.append((routing["global"], routing["global_argmax"], routing["global_margin"]))
+    for given, own, margin in pairs:
+        diff = given != own
+        n_all += diff.numel()
+        if diff.any():
+            # EXACT ties in the oracle (margin 0: the constant rows behind an all-zero spectrum, 10 % of the synthetic
+            # batch - every position of such a row holds the same value and receives the same upstream gradient) are
+            # counted apart: which of the equal positions a transform-domain convolution's rounding favours is free
+            n_tied += int((diff & (margin == 0)).sum())
+            n_bad += int((diff & (margin > 0)).sum())
+            worst = max(worst, float(margin[diff].max()))
+    assert worst <= max_margin, f"a max-pool window with a clear winner was routed differently (margin {worst:.2e})"
+    assert n_bad <= max(2, max_frac * n_all), f"{n_bad} of {n_all} max-pool windows routed differently ({n_tied} exact ties apart)"
+    routing["n_exact_ties_routed_differently"] = n_tied
+    return n_bad, n_all, worst
+
+
+def relu_gate_mismatches(gates, max_margin=1e-3, max_frac=1e-3):
+    """After an oracle forward under oracle.functional.RELU_GATES = gates: gates that differ from the oracle's own,
+    asserting each differing unit's pre-activation is within max_margin of zero (relative to the tensor's max-abs)
+    and that they are few."""
+    n_bad = n_all = 0
+    worst = 0.0
+    for site, seen in gates.get("_seen", {}).items():
+        given = gates.get(site)
+        if given is None:
+            continue
+        assert len(given) == len(seen), (site, len(given), len(seen))
+        for g, (own, mag) in zip(given, seen):
+            diff = g.reshape(own.shape) != own
+            n_all += diff.numel()
+            if diff.any():
+                n_bad += int(diff.sum())
+                worst = max(worst, float(mag[diff].max()))
+    assert worst <= max_margin, f"a ReLU gate with a clear sign differs (|pre| / max = {worst:.2e})"
+    assert n_bad <= max(4, max_frac * n_all), f"{n_bad} of {n_all} ReLU gates differ"
+    return n_bad, n_all, worst

@@ -301,9 +301,33 @@ def test_applecider_fusion_vs_oracle(dev, mode):
         Hm.set_math("f32")
 
 
+def _oracle_under_product_decisions(tap, osd, args, ocfg, tag):
+    """The oracle's 4-modality forward with the two kinds of discontinuous decisions taken as the PRODUCT took them:
+    max-pool routing (spectra branch) and ReLU gates (encoder feed-forward, image head).  Asserts that every decision
+    that differs from the oracle's own was a near-tie / near-zero and that they are few; what is left to compare is
+    arithmetic, which must then hold the tight bound on every gradient tensor."""
+    from common import relu_gate_mismatches, routing_mismatches
+    from oracle import functional as O
+    ocfg["routing"] = tap.routing()
+    gates = tap.relu_gates()
+    assert len(gates["encoder_ff"]) == ocfg["p_n_layers"] and len(gates["image_head"]) == 1
+    O.RELU_GATES = gates
+    try:
+        ref = O.applecider_forward(osd, *args, ocfg)
+    finally:
+        O.RELU_GATES = None
+    nb, na, w = routing_mismatches(ocfg["routing"])
+    gb, ga, gw = relu_gate_mismatches(gates)
+    print(f"[{tag}] decisions taken differently: {nb} of {na} max-pool windows (worst margin {w:.1e}, "
+          f"{ocfg['routing']['n_exact_ties_routed_differently']} exact ties apart), {gb} of {ga} ReLU gates "
+          f"(worst |pre| / max {gw:.1e})")
+    return ref
+
+
 def _fusion_vs_oracle(dev, mode="f32"):
     from applecider_amd.models.applecider import AppleCider
     from applecider_amd.synthetic import make_batch
+    from common import routing_mismatches, routing_tap
     from oracle import functional as O
     for fusion in ("avg", "concat"):
         fc = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.0,
@@ -318,10 +342,13 @@ def _fusion_vs_oracle(dev, mode="f32"):
         ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": fusion,
                 "kernel_sizes_per_stage": cfg_default()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
         osd = {k: v.clone().requires_grad_() for k, v in sd.items()}
-        ref = O.applecider_forward(osd, *args, ocfg)
+        with routing_tap() as tap:
+            logits = m(*[a.to(dev) for a in args])
+        # the oracle under the product's max-pool routing (tests/common.py routing_tap): removes the one effect that
+        # made the spectra-branch gradients incomparable at B = 4 (a near-tie window sending its gradient elsewhere)
+        ref = _oracle_under_product_decisions(tap, osd, args, ocfg, f"fusion vs oracle {mode} {fusion}")
         ref_loss = F.cross_entropy(ref, labels)
         ref_loss.backward()
-        logits = m(*[a.to(dev) for a in args])
         assert_close(logits, ref, LOGIT_TOL, f"{fusion} logits")
         assert np.array_equal(logits.argmax(1).cpu().numpy(), ref.argmax(1).numpy())
         from applecider_amd import hipops as H
@@ -330,43 +357,71 @@ def _fusion_vs_oracle(dev, mode="f32"):
         m.optimizer.zero_grad()
         loss.backward()
         gr = grads_by_ref_name(m)
-        checked, loose = 0, []
+        checked = 0
         for k, ref_t in osd.items():
             if ref_t.grad is None or k not in gr:
                 continue
-            if mode == "bf16x3" and "spectra_encoder.all_stages" not in k:
-                # Split-bf16 products differ from fp32 by ~2e-5 instead of ~5e-7, so at B = 4 a few ReLU
-                # gates of the encoder feed-forward / the image head sit on the other side of zero than in the
-                # CPU run (the same discontinuity argument as for the max-pool below, one flipped gate moves
-                # one row of dW by O(1/B)): every tensor keeps the aggregate bound, and all but a few the
-                # tight one.
-                a, r = gr[k].detach().cpu().double().flatten(), ref_t.grad.double().flatten()
-                cos = float((a @ r) / (a.norm() * r.norm() + 1e-300))
-                assert cos >= 0.9995, f"{fusion} grad {k}: cosine {cos}"
-                assert_close(gr[k], ref_t.grad, 3e-2, f"{fusion} grad {k}")
-                e = float((a - r).abs().max() / r.abs().max().clamp_min(1e-30))
-                if e > 5e-3:
-                    loose.append((k, e))
-                checked += 1
-                continue
-            if "spectra_encoder.all_stages" in k:
-                # Upstream of MaxPool1d the gradient is discontinuous: a single window whose two
-                # largest values differ by less than fp32 rounding may route its gradient to the
-                # other position on the GPU (different summation order), which perturbs every
-                # upstream tensor by O(1/(B*L)).  Kernel-level tests pin each backward tightly; here
-                # we bound the aggregate: <= 3e-2 of max and cosine >= 0.9995.
-                a, r = gr[k].detach().cpu().double().flatten(), ref_t.grad.double().flatten()
-                cos = float((a @ r) / (a.norm() * r.norm() + 1e-300))
-                assert cos >= 0.9995, f"{fusion} grad {k}: cosine {cos}"
-                # (bf16x3: ~40x more windows inside the rounding band than in fp32 mode, each flip moves its
-                # tensors by O(1/(B*L)) at B = 4; the direction stays pinned by the cosine)
-                assert_close(gr[k], ref_t.grad, 8e-2 if mode == "bf16x3" else 3e-2, f"{fusion} grad {k}")
-            else:
-                assert_close(gr[k], ref_t.grad, 5e-3, f"{fusion} grad {k}")
+            # every tensor, both modes, one bound: with the max-pool routing and the ReLU gates pinned nothing needs the
+            # looser classes of round 3 (3e-2 / 8e-2 + cosine for the spectra branch, 3e-2 for <= 3 % of the others)
+            assert_close(gr[k], ref_t.grad, 5e-3, f"{fusion} grad {k}")
             checked += 1
         assert checked > 400
-        print(f"[fusion vs oracle] {mode} {fusion}: {checked} gradients, beyond 5e-3: {loose}")
-        assert len(loose) <= 0.03 * checked, loose
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_applecider_fusion_gradients_tight_at_batch_64(dev, mode):
+    """backward parity of the benchmarked mode held tightly.  Full-size 4-modality model, B = 64
+    max-pool routing and ReLU gates pinned to the product's (routing_tap; the differing ones are shown to be near-ties /
+    near-zero and few): EVERY one of the ~460
+    gradient tensors within 5e-3 of the oracle's in both qualified modes (no looser class), logits 1e-3, labels equal.
+    Per-tensor errors are written to gpurun_out/parity_golden_modes.json."""
+    from applecider_amd import hipops as H
+    from applecider_amd.models.applecider import AppleCider
+    from applecider_amd.synthetic import make_batch
+    from common import routing_mismatches, routing_tap
+    from oracle import functional as O
+    H.set_math(mode)
+    set_context("applecider_fusion_gradients_B64", mode)
+    try:
+        fc = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.0,
+              "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3}
+        m = AppleCider(fc)
+        sd = closed_form_sd(m)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        Bn = 64
+        b = make_batch(Bn, seed=64)
+        args = [T(b[k]) for k in ("photometry", "pad_mask", "metadata", "image", "spectra")]
+        labels = T(b["label"])
+        with routing_tap() as tap:
+            logits = m(*[a.to(dev) for a in args])
+        loss = H.cross_entropy_index(logits, labels.to(dev))
+        m.optimizer.zero_grad()
+        loss.backward()
+        gr = grads_by_ref_name(m)
+        ocfg = {"p_n_heads": 8, "p_n_layers": 4, "fusion": "avg",
+                "kernel_sizes_per_stage": cfg_default()["model"]["SpectraNet"]["kernel_sizes_per_stage"]}
+        osd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        from oracle.cpu_baseline import usable_cores
+        torch.set_num_threads(usable_cores())      # (the affinity mask of a GPU box lists every host core)
+        ref = _oracle_under_product_decisions(tap, osd, args, ocfg, f"fusion B=64 {mode}")
+        F.cross_entropy(ref, labels).backward()
+        assert_close(logits, ref, LOGIT_TOL, "logits")
+        assert np.array_equal(logits.argmax(1).cpu().numpy(), ref.argmax(1).numpy())
+        checked, worst_t = 0, ("", 0.0)
+        for k, ref_t in osd.items():
+            if ref_t.grad is None or k not in gr:
+                continue
+            assert_close(gr[k], ref_t.grad, 5e-3, "grad " + k)
+            e = float((gr[k].detach().cpu().double() - ref_t.grad.double()).abs().max() / ref_t.grad.double().abs().max().clamp_min(1e-30))
+            if e > worst_t[1]:
+                worst_t = (k, e)
+            checked += 1
+        assert checked > 400
+        print(f"[fusion B=64] {mode}: {checked} gradients <= 5e-3 (worst {worst_t[0]}: {worst_t[1]:.2e})")
+    finally:
+        set_context(None, None)
+        H.set_math("f32")
 
 
 def test_applecider_train_step_bf16_runs(dev):
@@ -554,19 +609,33 @@ def test_spectranet_redshift_golden(dev, gmode):
     from applecider_amd.models.spectranet import SpectraNet
     from applecider_amd.training import MSELoss, attach_defaults
     from test_oracle_golden import _g14_setup
+    from common import routing_mismatches, routing_tap
+    from oracle import functional as O
     g, cfg, flux, label, z = _g14_setup()
     m = build(SpectraNet, cfg, dev).eval()
     batch = (T(flux).to(dev), T(label).to(dev), T(z).to(dev))
-    y = m(batch)
+    with routing_tap() as tap:
+        y = m(batch)
     assert tuple(y.shape) == (4,)
     assert_close(y, g["pred"], LOGIT_TOL, "pred")
     loss = H.mse_loss(y, batch[2])
     assert_close(loss, g["mse"], LOGIT_TOL, "mse")
     loss.backward()
     gr = grads_by_ref_name(m)
+    # gradients: tight against the oracle evaluated under the product's max-pool routing (the oracle under its own
+    # routing IS the golden: tests/test_oracle_golden.py); against the golden itself tight when no window was routed
+    # differently, else the windows must be near-ties and few, and the golden bound is the aggregate one
+    osd = {k: v.clone().requires_grad_() for k, v in closed_form_sd(SpectraNet(cfg)).items()}
+    routing = tap.routing()
+    ks = cfg["model"]["SpectraNet"]["kernel_sizes_per_stage"]
+    F.mse_loss(O.spectranet_forward(osd, T(flux), ks, head="regressor", routing=routing), T(z)).backward()
+    n_bad, n_all, worst = routing_mismatches(routing)
+    print(f"[g14 {gmode}] {n_bad} of {n_all} max-pool windows routed differently (worst margin {worst:.1e})")
     for k in g.files:
         if k.startswith("grad."):
-            assert_close(compact(gr[k[5:]].detach().cpu().numpy()), g[k], GRAD_TOL, k)
+            got = gr[k[5:]].detach().cpu()
+            assert_close(got, osd[k[5:]].grad, GRAD_TOL, k + " (oracle, product routing)")
+            assert_close(compact(got.numpy()), g[k], GRAD_TOL if n_bad == 0 else 3e-2, k)
     m = attach_defaults(build(SpectraNet, cfg, dev).eval())
     assert isinstance(m.criterion, MSELoss)
     l1 = m.train_step(batch)["loss"]
@@ -576,7 +645,9 @@ def test_spectranet_redshift_golden(dev, gmode):
     sd = m.state_dict()
     for k in g.files:
         if k.startswith("after_step2."):
-            assert_close(compact(sd[k[12:]].detach().cpu().numpy()), g[k], 1e-3, k)
+            # (a window routed differently in the first step moves the stage weights behind it by lr * that gradient)
+            tol = 1e-2 if (n_bad and "all_stages" in k) else 1e-3
+            assert_close(compact(sd[k[12:]].detach().cpu().numpy()), g[k], tol, k)
     with torch.no_grad():
         assert_close(m(batch), g["pred_after_step2"], 5e-3, "pred after two SGD steps")
 
