@@ -175,7 +175,10 @@ SIGNATURES = {
     "ac_ceil_copy": [_P, _P, _I64, _P],
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_gemm_batched": [C.POINTER(GemmDesc), _I32, _I64, _I64, _I64, _P],
-    "ac_ln_gelu_pw_pool_fwd": [_P, _I64, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    "ac_spectail_supported": [_I64, _I32, _I32],
+    "ac_spectail_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    "ac_spectail_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _I32, _I32, _P],
+    "ac_spectail_bwd_dw": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_fft_rows_fwd": [C.POINTER(FftRowsDesc), _P],
     "ac_fft_rows_inv": [C.POINTER(FftRowsDesc), _P],
     "ac_fft_taps_fwd": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],

@@ -1,18 +1,24 @@
-// Tail of a SpectraNetBlock in ONE forward kernel (gfx950, split-bf16 arithmetic):
-//     pooled = MaxPool1d(4)( Conv1d_1x1( GELU( LayerNorm(ycat) ) ) )        src/applecider/models/spectranet.py:31-40
-// ycat [R, K] are the concatenated conv outputs (R = B * L rows, K = 3 * Cout channels), w [N, K] the 1x1 taps.
-// Unfused, the three kernels move ycat (read) + z (written, read) + the 1x1 output (written, read) + the pooled rows:
-// 6.0 GB at stage 1 of the default configuration (R = 2 097 152, K = 192, N = 64); here ycat is read from HBM once
-// (statistics), again from L2 (the K loop), z is written once because the weight gradient of the 1x1 conv needs it,
-// and only the pooled rows + argmax bytes leave: 3.4 GB.
+// Tail of a pooled SpectraNetBlock (src/applecider/models/spectranet.py:31-40), gfx950, split-bf16 arithmetic:
+//     pooled = MaxPool1d(4)( Conv1d_1x1( GELU( LayerNorm_C(ycat) ) ) )
+// ycat [rows, K] are the concatenated conv outputs (rows = B * L, K = 3 * Cout channels), w [N, K] the 1x1 taps,
+// N = Cout.  Unfused, the forward pass moved ycat (read) + z = gelu(LN(ycat)) (written, read) + the 1x1 output
+// (written, read) and the backward pass un-pooled into a full-size tensor, read z and that tensor for the 1x1 conv's
+// weight gradient, wrote and re-read d z, and re-read ycat in LayerNorm's backward: 15.8 GB per step at stage 1 of the
+// default configuration (rows = 2 097 152, K = 192, N = 64).  Here NOTHING of row length K is written in the forward
+// pass and nothing but the (hi, lo) operand planes of d ycat in the backward pass; z and d(1x1 output) only ever exist
+// as bf16 (hi, lo) planes of 32 rows in LDS:
+//   tail_fwd     ycat -> statistics -> z planes -> z . w^T (+ bias) -> max over 4 rows: pooled, argmax, mean, rstd
+//   tail_bwd_dx  (ycat, mean, rstd, d pooled, argmax) -> d z = scatter(d pooled) . w -> GELU', LayerNorm backward ->
+//                (hi, lo) planes of d ycat (zero-padded layout of the conv bank's gradient products), d gamma, d beta,
+//                column sums of d ycat (the conv biases' gradient)
+//   tail_bwd_dw  (ycat, mean, rstd, d pooled, argmax) -> z planes again -> d w += scatter(d pooled)^T . z
+// 6.9 GB at stage 1.  Every product is three bf16 MFMAs on (hi, lo) halves (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32
+// accumulate), as everywhere in this mode.
 //
-// Structure = the 128 x 128 x 32 split-bf16 product of ac_gemm.hip (four bf16 images per stage: A_hi, A_lo, B_hi,
-// B_lo; three MFMAs per fragment pair; two LDS stages, loads two K tiles ahead) with
-//   * a prologue: the workgroup's 128 rows' mean / rstd (16 lanes per row, two passes over the row: the second one
-//     hits L1 / L2), kept in LDS and written out for the backward pass;
-//   * a transform where the A registers are split into planes: z = gelu((x - mean) * rstd * gamma + beta);
-//   * an epilogue: the 128 x 128 accumulator tile (+ bias) goes through LDS, four consecutive rows are reduced to
-//     their maximum (first index on ties, NaN wins: torch's rule) and only the pooled row and its argmax are stored.
+// One workgroup owns blocks of R = 32 whole rows and walks several of them (next block's rows are loaded into
+// registers while this block is in the matrix cores); a row is spread over TPR adjacent lanes, so statistics and
+// LayerNorm's row sums are sub-wave shuffles.  Supported shapes: (K, N) = (192, 64) and (384, 128) - stages 1 and 2
+// hold 75 % of the tails' bytes; stages 3 and 4 are matrix-core-bound at these row counts and keep their products.
 #include "ac_common.h"
 
 namespace {
@@ -22,22 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BK = 32;
-constexpr int IMG = 128 * 32;                       // bf16 elements of one operand image
-constexpr int STAGE = 4 * IMG;                      // A_hi, A_lo, B_hi, B_lo
-constexpr int KMAX = 1536;                          // widest concatenated row (stage 4 of the default configuration)
-constexpr int LDS_BYTES = 2 * STAGE * 2 + 2 * BM * 4 + 2 * KMAX * 4;   // two stages + mean / rstd of the 128 rows + gamma, beta
-
-struct TailParams {
-    const float *ycat;
-    int64_t ld;
-    const float *gamma, *beta, *w, *bias;
-    float *z, *mean, *rstd, *pooled;
-    uint8_t *idx;
-    int R, K, N;
-    float eps;
-    int tiles_m, tiles_n;
-};
+constexpr int R = 32;                                   // rows per block = one 32-row MFMA tile
 
 __device__ __forceinline__ void split4(const f32x4 &v, s16x4 &hi, s16x4 &lo) {
 #pragma unroll
@@ -47,240 +38,472 @@ __device__ __forceinline__ void split4(const f32x4 &v, s16x4 &hi, s16x4 &lo) {
         lo[j] = (short)ac_f2h(v[j] - ac_h2f(h));
     }
 }
-// [128 rows][32 k] bf16 image: 16-byte chunks (8 k) swizzled by (row >> 2) & 3; thread chunk c (4 floats) = half a chunk
-__device__ __forceinline__ int kc_off(int r, int c) { return r * 32 + (((c >> 1) ^ ((r >> 2) & 3)) << 3) + (c & 1) * 4; }
-__device__ __forceinline__ bf16x8 frag_kc(const unsigned short *img, int rowbase, int s, int lane) {
-    const int local = rowbase + (lane & 31), lh = lane >> 5;
-    const int chunk16 = (2 * s + lh) ^ ((local >> 2) & 3);
-    return *(const bf16x8 *)(img + local * 32 + chunk16 * 8);
-}
-__device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {   // sum over G adjacent lanes (G = 8, 16, 32)
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// NB = 32-column blocks per wave: 2 -> 128-column tiles, 1 -> 64-column tiles (stage 1: N = 64)
-template <int NB>
-__global__ __launch_bounds__(256, 2) void ln_gelu_pw_pool_fwd_kernel(TailParams p) {
-    constexpr int BN = 64 * NB, NG = 2 * NB;      // tile columns, 32-row groups of w per tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned short *sm16 = reinterpret_cast<unsigned short *>(smem);
-    float *s_mean = smem + (2 * STAGE * 2) / 4, *s_rstd = s_mean + BM, *s_gamma = s_rstd + BM, *s_beta = s_gamma + KMAX;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
-    const int row0 = tm * BM, K = p.K;
+// fragment of a [rows][k] plane, row-major ("k contiguous"): lane -> row base + (lane & 31), k = 16 s + 8 (lane >> 5) ..+7
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned short *plane, int rowbase, int s, int lane) {
+    return *(const bf16x8 *)(plane + (rowbase + (lane & 31)) * PITCH + 16 * s + 8 * (lane >> 5));
+}
+// fragment of a [k][cols] plane (the reduction index is the ROW of the plane): hardware transpose read,
+// lane -> col base + (lane & 31), k = 16 s + 8 (lane >> 5) ..+7
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_rc(const unsigned short *plane, int colbase, int s, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int k0 = 16 * s + 8 * (g >> 1);
+    const unsigned short *a0 = plane + (k0 + q) * PITCH + colbase + 16 * (g & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a0 + 4 * PITCH));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
 
-    for (int k = 4 * t; k < K; k += 4 * 256) {
-        *(f32x4 *)(s_gamma + k) = ac_gload<f32x4>(p.gamma + k);
-        *(f32x4 *)(s_beta + k) = ac_gload<f32x4>(p.beta + k);
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+
+// three-MFMA product of split operands: cross terms first, the leading term last
+__device__ __forceinline__ f32x16 mma3(const bf16x8 &ah, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bl, f32x16 acc) {
+    acc = AC_MFMA16(al, bh, acc);
+    acc = AC_MFMA16(ah, bl, acc);
+    acc = AC_MFMA16(ah, bh, acc);
+    return acc;
+}
+
+struct TailParams {
+    const float *ycat, *gamma, *beta, *bias;
+    const unsigned short *w_hi, *w_lo;      // fwd: planes of w [N][K]; bwd_dx: planes of w^T [K][N]
+    float *mean, *rstd, *pooled;            // fwd outputs (bwd: mean / rstd are inputs)
+    uint8_t *idx;
+    const float *dpooled;
+    unsigned short *dx_hi, *dx_lo;
+    float *dgamma, *dbeta, *dxsum, *dw;
+    int64_t rows;
+    int nblocks, seg_len, seg_pitch, seg_off;
+    float eps;
+};
+
+// ---- the rows of one block in registers: thread (r = t / TPR, sub = t % TPR) holds float4s at columns 4 (sub + TPR j)
+template <int K, int TPR>
+struct RowRegs {
+    static constexpr int NV = K / (4 * TPR);
+    f32x4 v[NV];
+    __device__ __forceinline__ void load(const float *ycat, int64_t row, int sub) {
+        const float *p = ycat + row * K + 4 * sub;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = ac_gload<f32x4>(p + 4 * TPR * j);
     }
-    // ---- row statistics: 16 lanes per row, 4 rows per wave and sweep
+};
+
+// z = gelu((x - mu) rs gamma + beta) of this thread's elements -> (hi, lo) planes [R][ZP] in LDS
+template <int K, int TPR, int ZP>
+__device__ __forceinline__ void write_z_planes(const RowRegs<K, TPR> &x, float mu, float rs, const float *s_gamma,
+                                               const float *s_beta, unsigned short *zhi, unsigned short *zlo, int r,
+                                               int sub) {
+#pragma unroll
+    for (int j = 0; j < RowRegs<K, TPR>::NV; ++j) {
+        const int c = 4 * (sub + TPR * j);
+        const f32x4 g = *(const f32x4 *)(s_gamma + c), b = *(const f32x4 *)(s_beta + c);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = ac_gelu_fast((x.v[j][e] - mu) * rs * g[e] + b[e]);
+        s16x4 hi, lo;
+        split4(z, hi, lo);
+        *(s16x4 *)(zhi + r * ZP + c) = hi;
+        *(s16x4 *)(zlo + r * ZP + c) = lo;
+    }
+}
+
+// d(1x1 output) of one block = the pooled gradient scattered to the arg-max row of each window, as (hi, lo) planes
+// [R][DP]: work item (pooled row pr < 8, four channels n4)
+template <int N, int DP, int NT>
+__device__ __forceinline__ void write_dout_planes(const float *dpooled, const uint8_t *idx, int64_t prow0,
+                                                  unsigned short *dhi, unsigned short *dlo, int t) {
+    for (int i = t; i < (R / 4) * (N / 4); i += NT) {
+        const int pr = i / (N / 4), n = 4 * (i - pr * (N / 4));
+        const f32x4 g = ac_gload<f32x4>(dpooled + (prow0 + pr) * N + n);
+        const uchar4 a = *(const uchar4 *)(idx + (prow0 + pr) * N + n);
+        s16x4 hi, lo;
+        split4(g, hi, lo);
+        const unsigned am[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = am[e] == (unsigned)j ? hi[e] : (short)0;
+                l[e] = am[e] == (unsigned)j ? lo[e] : (short)0;
+            }
+            *(s16x4 *)(dhi + (4 * pr + j) * DP + n) = h;
+            *(s16x4 *)(dlo + (4 * pr + j) * DP + n) = l;
+        }
+    }
+}
+
+// =====================================================================================================================
+// forward: NT = 64 * 2 * (N / 32) threads; wave w -> output tile (all 32 rows) x (32 channels nt = w % MT), half
+// kh = w / MT of the reduction; its w fragments stay in registers for the whole launch
+// =====================================================================================================================
+template <int K, int N>
+__global__ __launch_bounds__(128 * (N / 32)) void tail_fwd_kernel(TailParams p) {
+    constexpr int MT = N / 32, NT = 128 * MT, TPR = NT / R, ZP = K + 8, KS = K / 32;
+    static_assert(K % (4 * TPR) == 0 && (ZP * 2) % 16 == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short *zhi = (unsigned short *)smem_raw, *zlo = zhi + R * ZP;
+    float *red = (float *)(zlo + R * ZP);                     // [MT][16][64]
+    float *s_gamma = red + MT * 16 * 64, *s_beta = s_gamma + K;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, lh = lane >> 5;
+    const int r = t / TPR, sub = t % TPR, nt = w % MT, kh = w / MT;
+
+    for (int c = 4 * t; c < K; c += 4 * NT) {
+        *(f32x4 *)(s_gamma + c) = ac_gload<f32x4>(p.gamma + c);
+        *(f32x4 *)(s_beta + c) = ac_gload<f32x4>(p.beta + c);
+    }
+    bf16x8 wh[KS], wl[KS];
     {
-        const int l16 = lane & 15, sub = lane >> 4;
-        const float invK = 1.0f / (float)K;
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int lr = wave * 32 + it * 4 + sub;
-            const float *xr = p.ycat + (int64_t)(row0 + lr) * p.ld;
-            float s = 0.f;
-            for (int c = l16 * 4; c < K; c += 64) {
-                const f32x4 v = ac_gload<f32x4>(xr + c);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
+        const int64_t off = (int64_t)(nt * 32 + (lane & 31)) * K + 16 * (kh * KS) + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            wh[s] = ac_gload<bf16x8>((const short *)p.w_hi + off + 16 * s);
+            wl[s] = ac_gload<bf16x8>((const short *)p.w_lo + off + 16 * s);
+        }
+    }
+    const float bias = (kh == 0 && p.bias) ? p.bias[nt * 32 + (lane & 31)] : 0.f;
+    const float invK = 1.0f / (float)K;
+    RowRegs<K, TPR> x;
+    int blk = blockIdx.x;
+    if (blk < p.nblocks) x.load(p.ycat, (int64_t)blk * R + r, sub);
+    __syncthreads();
+    for (; blk < p.nblocks; blk += gridDim.x) {
+        const int64_t row0 = (int64_t)blk * R;
+        // ---- statistics of this thread's row (two passes over the registers), z planes
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < x.NV; ++j) s += (x.v[j][0] + x.v[j][1]) + (x.v[j][2] + x.v[j][3]);
+        const float mu = group_sum<TPR>(s) * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < x.NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = x.v[j][e] - mu;
+                q += d * d;
             }
-            const float mean = sum16(s) * invK;
-            float qs = 0.f;
-            for (int c = l16 * 4; c < K; c += 64) {
-                const f32x4 v = ac_gload<f32x4>(xr + c);
-                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-                qs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-            const float rstd = rsqrtf(sum16(qs) * invK + p.eps);
-            if (l16 == 0) {
-                s_mean[lr] = mean;
-                s_rstd[lr] = rstd;
-                if (tn == 0) {
-                    p.mean[row0 + lr] = mean;
-                    p.rstd[row0 + lr] = rstd;
+        const float rs = rsqrtf(group_sum<TPR>(q) * invK + p.eps);
+        if (sub == 0) {
+            p.mean[row0 + r] = mu;
+            p.rstd[row0 + r] = rs;
+        }
+        write_z_planes<K, TPR, ZP>(x, mu, rs, s_gamma, s_beta, zhi, zlo, r, sub);
+        if (blk + (int)gridDim.x < p.nblocks) x.load(p.ycat, (int64_t)(blk + gridDim.x) * R + r, sub);
+        __syncthreads();
+        // ---- z . w^T over this wave's half of the channels
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const bf16x8 ah = frag_kc<ZP>(zhi, 0, kh * KS + s2, lane), al = frag_kc<ZP>(zlo, 0, kh * KS + s2, lane);
+            acc = mma3(ah, al, wh[s2], wl[s2], acc);
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(nt * 16 + e) * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            // rows of acc[e]: 8 (e >> 2) + 4 lh + (e & 3): each group of four e is one pooling window
+            const int64_t prow0 = row0 >> 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m = acc[4 * g] + red[(nt * 16 + 4 * g) * 64 + lane] + bias;
+                unsigned am = 0;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const float v = acc[4 * g + j] + red[(nt * 16 + 4 * g + j) * 64 + lane] + bias;
+                    if (v > m || (v != v && m == m)) {      // first maximum wins, NaN propagates (torch's rule)
+                        m = v;
+                        am = j;
+                    }
                 }
+                const int64_t o = (prow0 + 2 * g + lh) * N + nt * 32 + (lane & 31);
+                p.pooled[o] = m;
+                p.idx[o] = (uint8_t)am;
             }
         }
     }
+}
+
+// =====================================================================================================================
+// backward, weight gradient of the 1x1 conv: d w [N][K] += d out^T [N][rows] . z [rows][K].  NT as in the forward
+// kernel; wave w -> rows mt = w % MT of d w (32 output channels), columns half = w / MT (K / 64 tiles of 32)
+// =====================================================================================================================
+template <int K, int N>
+__global__ __launch_bounds__(128 * (N / 32)) void tail_bwd_dw_kernel(TailParams p) {
+    constexpr int MT = N / 32, NT = 128 * MT, TPR = NT / R, ZP = K + 8, DP = N + 8, CT = K / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short *zhi = (unsigned short *)smem_raw, *zlo = zhi + R * ZP, *dhi = zlo + R * ZP, *dlo = dhi + R * DP;
+    float *s_gamma = (float *)(dlo + R * DP), *s_beta = s_gamma + K;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, lh = lane >> 5;
+    const int r = t / TPR, sub = t % TPR, mt = w % MT, half = w / MT;
+
+    for (int c = 4 * t; c < K; c += 4 * NT) {
+        *(f32x4 *)(s_gamma + c) = ac_gload<f32x4>(p.gamma + c);
+        *(f32x4 *)(s_beta + c) = ac_gload<f32x4>(p.beta + c);
+    }
+    f32x16 acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = zero16();
+    RowRegs<K, TPR> x;
+    int blk = blockIdx.x;
+    if (blk < p.nblocks) x.load(p.ycat, (int64_t)blk * R + r, sub);
     __syncthreads();
+    for (; blk < p.nblocks; blk += gridDim.x) {
+        const int64_t row0 = (int64_t)blk * R;
+        const float mu = p.mean[row0 + r], rs = p.rstd[row0 + r];
+        write_z_planes<K, TPR, ZP>(x, mu, rs, s_gamma, s_beta, zhi, zlo, r, sub);
+        write_dout_planes<N, DP, NT>(p.dpooled, p.idx, row0 >> 2, dhi, dlo, t);
+        if (blk + (int)gridDim.x < p.nblocks) x.load(p.ycat, (int64_t)(blk + gridDim.x) * R + r, sub);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < R / 16; ++s) {
+            const bf16x8 ah = frag_rc<DP>(dhi, mt * 32, s, lane), al = frag_rc<DP>(dlo, mt * 32, s, lane);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const bf16x8 bh = frag_rc<ZP>(zhi, (half * CT + j) * 32, s, lane);
+                const bf16x8 bl = frag_rc<ZP>(zlo, (half * CT + j) * 32, s, lane);
+                acc[j] = mma3(ah, al, bh, bl, acc[j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = mt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3), kk = (half * CT + j) * 32 + (lane & 31);
+            atomicAdd(p.dw + (int64_t)n * K + kk, acc[j][e]);
+        }
+}
 
-    // ---- K loop.  This thread's rows are rbase + 32 i, its k chunk c of every tile.  N % 32 == 0: a group of 32 rows
-    // of w is inside the matrix or outside it as a whole (bvalid: uniform over the workgroup).
-    const int c = t & 7, rbase = t >> 3;
-    const float *a0 = p.ycat + (int64_t)(row0 + rbase) * p.ld + 4 * c;
-    const float *b0p = p.w + (int64_t)(tn * BN + rbase) * K + 4 * c;
-    const int64_t astep = 32 * p.ld, bstep = (int64_t)32 * K;
-    const int64_t zdelta = p.z ? p.z - p.ycat : 0;           // ld == K: z has the layout of ycat
-    const bool write_z = p.z != nullptr && tn == 0;
-    const int bgroups = (p.N - tn * BN + 31) / 32;           // groups of 32 rows of w this tile holds (1 .. NG)
-    const int nkt = K / BK;
+// =====================================================================================================================
+// backward, gradient of the conv outputs: 512 threads (16 per row: K / 64 float4 per thread); wave w owns the
+// 32-column tiles w, w + 8, ... of d z = d out [R][N] . w [N][K]; then every thread finishes LayerNorm's backward for its
+// elements
+// =====================================================================================================================
+template <int K, int N>
+__global__ __launch_bounds__(512) void tail_bwd_dx_kernel(TailParams p) {
+    constexpr int TPR = 16, NT = TPR * R, NW = NT / 64, DP = N + 8, ZF = K + 4, KS = N / 16, NV = K / (4 * TPR);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *dz = (float *)smem_raw;                                   // [R][ZF] fp32
+    float *sacc = dz + R * ZF;                                       // [3][K]
+    float *s_gamma = sacc + 3 * K, *s_beta = s_gamma + K;
+    unsigned short *dhi = (unsigned short *)(s_beta + K), *dlo = dhi + R * DP;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, lh = lane >> 5;
+    const int r = t / TPR, sub = t % TPR;
 
-    f32x16 acc[2][NB];
+    for (int c = 4 * t; c < K; c += 4 * NT) {
+        *(f32x4 *)(s_gamma + c) = ac_gload<f32x4>(p.gamma + c);
+        *(f32x4 *)(s_beta + c) = ac_gload<f32x4>(p.beta + c);
+    }
+    for (int c = t; c < 3 * K; c += NT) sacc[c] = 0.f;
+    f32x4 adg[NV], adb[NV], adx[NV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NV; ++j) adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float invK = 1.0f / (float)K;
+    RowRegs<K, TPR> x;
+    int blk = blockIdx.x;
+    if (blk < p.nblocks) x.load(p.ycat, (int64_t)blk * R + r, sub);
+    __syncthreads();
+    for (; blk < p.nblocks; blk += gridDim.x) {
+        const int64_t row0 = (int64_t)blk * R;
+        write_dout_planes<N, DP, NT>(p.dpooled, p.idx, row0 >> 2, dhi, dlo, t);
+        const float mu = p.mean[row0 + r], rs = p.rstd[row0 + r];
+        __syncthreads();
+        for (int tile = w; tile < K / 32; tile += NW) {
+            // d z tile: reduction over the N output channels; B = planes of w^T [K][N] straight from L2
+            f32x16 acc = zero16();
+            const int64_t boff = (int64_t)(tile * 32 + (lane & 31)) * N + 8 * lh;
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 bh = ac_gload<bf16x8>((const short *)p.w_hi + boff + 16 * s);
+                const bf16x8 bl = ac_gload<bf16x8>((const short *)p.w_lo + boff + 16 * s);
+                const bf16x8 ah = frag_kc<DP>(dhi, 0, s, lane), al = frag_kc<DP>(dlo, 0, s, lane);
+                acc = mma3(ah, al, bh, bl, acc);
+            }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    struct Regs {
-        f32x4 a[4], b[NG];
-    };
-    auto load = [&](int kt, Regs &r) {
-        const int k = (kt < nkt ? kt : nkt - 1) * BK;       // clamped: a tile past the end is loaded, never stored
+            for (int e = 0; e < 16; ++e) dz[(8 * (e >> 2) + 4 * lh + (e & 3)) * ZF + tile * 32 + (lane & 31)] = acc[e];
+        }
+        __syncthreads();
+        // ---- LayerNorm backward of this thread's elements (ac_rows.hip layernorm_bwd_sub_kernel, with d y = d z)
+        f32x4 d[NV];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.a[i] = ac_gload<f32x4>(a0 + i * astep + k);
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (sub + TPR * j);
+            const f32x4 g = *(const f32x4 *)(s_gamma + c), b = *(const f32x4 *)(s_beta + c);
+            const f32x4 dzv = *(const f32x4 *)(dz + r * ZF + c);
 #pragma unroll
-        for (int i = 0; i < NG; ++i) r.b[i] = ac_gload<f32x4>(b0p + (i < bgroups ? i : 0) * bstep + k);
-    };
-    auto store = [&](int kt, unsigned short *stage, const Regs &r) {
-        unsigned short *ah = stage, *al = ah + IMG, *bh = ah + 2 * IMG, *bl = ah + 3 * IMG;
-        const f32x4 g = *(const f32x4 *)(s_gamma + kt * BK + 4 * c), bt = *(const f32x4 *)(s_beta + kt * BK + 4 * c);
+            for (int e = 0; e < 4; ++e) {
+                const float hh = (x.v[j][e] - mu) * rs;
+                const float dd = dzv[e] * ac_gelu_grad_fast(hh * g[e] + b[e]);
+                d[j][e] = dd * g[e];
+                s1 += d[j][e];
+                s2 += d[j][e] * hh;
+                adg[j][e] += dd * hh;
+                adb[j][e] += dd;
+            }
+        }
+        const float c1 = group_sum<TPR>(s1) * invK, c2 = group_sum<TPR>(s2) * invK;
+        const int64_t gr = row0 + r;
+        const int64_t rr = p.seg_len ? (gr / p.seg_len) * p.seg_pitch + p.seg_off + gr % p.seg_len : gr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float mu = s_mean[rbase + 32 * i], rs = s_rstd[rbase + 32 * i];
-            f32x4 zv;
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (sub + TPR * j);
+            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) zv[e] = ac_gelu_fast((r.a[i][e] - mu) * rs * g[e] + bt[e]);
-            if (write_z) *(f32x4 *)(const_cast<float *>(a0) + i * astep + kt * BK + zdelta) = zv;
+            for (int e = 0; e < 4; ++e) {
+                o[e] = rs * (d[j][e] - c1 - (x.v[j][e] - mu) * rs * c2);
+                adx[j][e] += o[e];
+            }
             s16x4 hi, lo;
-            split4(zv, hi, lo);
-            const int off = kc_off(rbase + 32 * i, c);
-            *(s16x4 *)(ah + off) = hi;
-            *(s16x4 *)(al + off) = lo;
-            if (i < NG) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                split4(i < bgroups ? r.b[i < NG ? i : 0] : zero, hi, lo);
-                *(s16x4 *)(bh + off) = hi;
-                *(s16x4 *)(bl + off) = lo;
-            }
+            split4(o, hi, lo);
+            *(s16x4 *)(p.dx_hi + rr * K + c) = hi;
+            *(s16x4 *)(p.dx_lo + rr * K + c) = lo;
         }
-    };
-    auto compute = [&](const unsigned short *stage) {
-        const unsigned short *ah = stage, *al = ah + IMG, *bh = ah + 2 * IMG, *bl = ah + 3 * IMG;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 fah[2], fal[2], fbh[NB], fbl[NB];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fah[i] = frag_kc(ah, wm * 64 + 32 * i, s, lane);
-                fal[i] = frag_kc(al, wm * 64 + 32 * i, s, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                fbh[j] = frag_kc(bh, wn * 32 * NB + 32 * j, s, lane);
-                fbl[j] = frag_kc(bl, wn * 32 * NB + 32 * j, s, lane);
-            }
-            // cross terms first, the leading term last
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = AC_MFMA16(fal[i], fbh[j], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = AC_MFMA16(fah[i], fbl[j], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = AC_MFMA16(fah[i], fbh[j], acc[i][j]);
-        }
-    };
-
-    unsigned short *S0 = sm16, *S1 = sm16 + STAGE;
-    Regs r0, r1;
-    load(0, r0);
-    store(0, S0, r0);
-    __syncthreads();
-    load(1, r0);
-    for (int kt = 0; kt < nkt; kt += 2) {
-        load(kt + 2, r1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(S0);
-        if (kt + 1 < nkt) store(kt + 1, S1, r0);
-        __syncthreads();
-        if (kt + 1 >= nkt) break;
-        load(kt + 3, r0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(S1);
-        if (kt + 2 < nkt) store(kt + 2, S0, r1);
-        __syncthreads();
+        if (blk + (int)gridDim.x < p.nblocks) x.load(p.ycat, (int64_t)(blk + gridDim.x) * R + r, sub);
     }
-
-    // ---- epilogue: tile (+ bias) -> LDS -> max over groups of four rows
-    float *tile = smem;                                     // 128 x BN fp32 over the stages (all reads done)
-    {
+    // ---- column sums: the 64 / TPR rows of a wave first (shuffles), then LDS, then one atomic per column and workgroup
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int col = wn * 32 * NB + 32 * j + li, n = tn * BN + col;
-            const float bj = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int sa = 0; sa < 2; ++sa)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    tile[(wm * 64 + sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * BN + col] = acc[sa][j][e] + bj;
+            for (int o = TPR; o < 64; o <<= 1) {
+                adg[j][e] += __shfl_xor(adg[j][e], o, 64);
+                adb[j][e] += __shfl_xor(adb[j][e], o, 64);
+                adx[j][e] += __shfl_xor(adx[j][e], o, 64);
+            }
+    __syncthreads();
+    if (lane < TPR) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (sub + TPR * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&sacc[c + e], adg[j][e]);
+                atomicAdd(&sacc[K + c + e], adb[j][e]);
+                atomicAdd(&sacc[2 * K + c + e], adx[j][e]);
+            }
         }
     }
     __syncthreads();
-    const int prow0 = row0 >> 2;
-    for (int i = t; i < (BM / 4) * BN; i += 256) {
-        const int pr = i / BN, col = i - pr * BN, n = tn * BN + col;
-        if (n >= p.N) continue;
-        float m = tile[(4 * pr) * BN + col];
-        unsigned am = 0;
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            const float v = tile[(4 * pr + j) * BN + col];
-            if (v > m || (v != v && m == m)) {
-                m = v;
-                am = j;
-            }
-        }
-        p.pooled[(int64_t)(prow0 + pr) * p.N + n] = m;
-        p.idx[(int64_t)(prow0 + pr) * p.N + n] = (uint8_t)am;
+    for (int c = t; c < K; c += NT) {
+        if (p.dgamma) atomicAdd(&p.dgamma[c], sacc[c]);
+        if (p.dbeta) atomicAdd(&p.dbeta[c], sacc[K + c]);
+        if (p.dxsum) atomicAdd(&p.dxsum[c], sacc[2 * K + c]);
     }
+}
+
+template <int K, int N>
+constexpr size_t fwd_lds() { return (size_t)2 * R * (K + 8) * 2 + (size_t)(N / 32) * 16 * 64 * 4 + (size_t)2 * K * 4; }
+template <int K, int N>
+constexpr size_t dw_lds() { return (size_t)2 * R * (K + 8) * 2 + (size_t)2 * R * (N + 8) * 2 + (size_t)2 * K * 4; }
+template <int K, int N>
+constexpr size_t dx_lds() { return (size_t)R * (K + 4) * 4 + (size_t)5 * K * 4 + (size_t)2 * R * (N + 8) * 2; }
+
+int grid_for(int nblocks, int per_cu) {
+    // persistent workgroups: a multiple of the 8 XCDs, ~per_cu per CU, every workgroup walks >= 2 blocks when it can
+    int g = 256 * per_cu;
+    if (g > nblocks) g = nblocks;
+    return g < 1 ? 1 : g;
+}
+
+template <auto KERNEL>
+int launch(int grid, int threads, size_t lds, const TailParams &p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e - 2000;
+        configured = true;
+    }
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(threads), lds, stream, p);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}
+
+bool shape_ok(int64_t rows, int K, int N) {
+    return rows > 0 && (rows % R) == 0 && rows / R <= 0x7FFFFFFF && ((K == 192 && N == 64) || (K == 384 && N == 128));
 }
 
 }  // namespace
 
-extern "C" int ac_ln_gelu_pw_pool_fwd(const float *ycat, int64_t ld, const float *gamma, const float *beta, float eps,
-                                      const float *w, const float *bias, float *z, float *mean, float *rstd,
-                                      float *pooled, uint8_t *idx, int64_t rows, int32_t K, int32_t N,
-                                      ac_stream_t stream) {
-    if (!ycat || !gamma || !beta || !w || !mean || !rstd || !pooled || !idx || rows <= 0 || K <= 0 || N <= 0)
+extern "C" int ac_spectail_supported(int64_t rows, int32_t K, int32_t N) { return shape_ok(rows, K, N) ? 1 : 0; }
+
+extern "C" int ac_spectail_fwd(const float *ycat, const float *gamma, const float *beta, float eps, const void *w_hi,
+                               const void *w_lo, const float *bias, float *mean, float *rstd, float *pooled,
+                               uint8_t *idx, int64_t rows, int32_t K, int32_t N, ac_stream_t stream) {
+    if (!ycat || !gamma || !beta || !w_hi || !w_lo || !mean || !rstd || !pooled || !idx || !shape_ok(rows, K, N))
         return AC_EINVAL;
-    if ((rows % BM) || (K % BK) || K < 2 * BK || K > KMAX || (N % 32) || ld != K ||
-        rows / BM * ((N + 63) / 64) > 0x7FFFFFFF)
-        return AC_EINVAL;
-    if ( !ac_aligned16(ycat) || !ac_aligned16(gamma) || !ac_aligned16(beta) || !ac_aligned16(w) ||
-        (z && !ac_aligned16(z)))
+    if (!ac_aligned16(ycat) || !ac_aligned16(gamma) || !ac_aligned16(beta) || !ac_aligned16(w_hi) || !ac_aligned16(w_lo))
         return AC_EALIGN;
-    TailParams p;
-    p.ycat = ycat; p.ld = ld; p.gamma = gamma; p.beta = beta; p.w = w; p.bias = bias;
-    p.z = z; p.mean = mean; p.rstd = rstd; p.pooled = pooled; p.idx = idx;
-    p.R = (int)rows; p.K = K; p.N = N; p.eps = eps;
-    const int bn = N <= 64 ? 64 : 128;
-    p.tiles_m = (int)(rows / BM); p.tiles_n = (N + bn - 1) / bn;
-    static const hipError_t attr1 = hipFuncSetAttribute((const void *)ln_gelu_pw_pool_fwd_kernel<1>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    static const hipError_t attr2 = hipFuncSetAttribute((const void *)ln_gelu_pw_pool_fwd_kernel<2>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (attr1 != hipSuccess) return -(int)attr1 - 2000;
-    if (attr2 != hipSuccess) return -(int)attr2 - 2000;
-    if (bn == 64)
-        hipLaunchKernelGGL(ln_gelu_pw_pool_fwd_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(ln_gelu_pw_pool_fwd_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
-    AC_CHECK_LAUNCH();
-    return AC_OK;
+    TailParams p = {};
+    p.ycat = ycat; p.gamma = gamma; p.beta = beta; p.bias = bias;
+    p.w_hi = (const unsigned short *)w_hi; p.w_lo = (const unsigned short *)w_lo;
+    p.mean = mean; p.rstd = rstd; p.pooled = pooled; p.idx = idx;
+    p.rows = rows; p.nblocks = (int)(rows / R); p.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 192) return launch<tail_fwd_kernel<192, 64>>(grid_for(p.nblocks, 4), 256, fwd_lds<192, 64>(), p, st);
+    return launch<tail_fwd_kernel<384, 128>>(grid_for(p.nblocks, 1), 512, fwd_lds<384, 128>(), p, st);
+}
+
+extern "C" int ac_spectail_bwd_dx(const float *ycat, const float *mean, const float *rstd, const float *gamma,
+                                  const float *beta, const float *dpooled, const uint8_t *idx, const void *wt_hi,
+                                  const void *wt_lo, void *dx_hi, void *dx_lo, int32_t seg_len, int32_t seg_pitch,
+                                  int32_t seg_off, float *dgamma, float *dbeta, float *dxsum, int64_t rows, int32_t K,
+                                  int32_t N, ac_stream_t stream) {
+    if (!ycat || !mean || !rstd || !gamma || !beta || !dpooled || !idx || !wt_hi || !wt_lo || !dx_hi || !dx_lo ||
+        !shape_ok(rows, K, N))
+        return AC_EINVAL;
+    if (seg_len < 0 || (seg_len > 0 && ((seg_len % R) || seg_pitch < seg_len + seg_off || seg_off < 0 || (rows % seg_len))))
+        return AC_EINVAL;
+    if (!ac_aligned16(ycat) || !ac_aligned16(gamma) || !ac_aligned16(beta) || !ac_aligned16(wt_hi) ||
+        !ac_aligned16(wt_lo) || !ac_aligned16(dpooled) || ((uintptr_t)idx & 3u) || ((uintptr_t)dx_hi & 7u) ||
+        ((uintptr_t)dx_lo & 7u))
+        return AC_EALIGN;
+    TailParams p = {};
+    p.ycat = ycat; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float *>(mean); p.rstd = const_cast<float *>(rstd);
+    p.w_hi = (const unsigned short *)wt_hi; p.w_lo = (const unsigned short *)wt_lo;
+    p.dpooled = dpooled; p.idx = const_cast<uint8_t *>(idx);
+    p.dx_hi = (unsigned short *)dx_hi; p.dx_lo = (unsigned short *)dx_lo;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dxsum = dxsum;
+    p.rows = rows; p.nblocks = (int)(rows / R); p.seg_len = seg_len; p.seg_pitch = seg_pitch; p.seg_off = seg_off;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 192) return launch<tail_bwd_dx_kernel<192, 64>>(grid_for(p.nblocks, 2), 512, dx_lds<192, 64>(), p, st);
+    return launch<tail_bwd_dx_kernel<384, 128>>(grid_for(p.nblocks, 1), 512, dx_lds<384, 128>(), p, st);
+}
+
+extern "C" int ac_spectail_bwd_dw(const float *ycat, const float *mean, const float *rstd, const float *gamma,
+                                  const float *beta, const float *dpooled, const uint8_t *idx, float *dw, int64_t rows,
+                                  int32_t K, int32_t N, ac_stream_t stream) {
+    if (!ycat || !mean || !rstd || !gamma || !beta || !dpooled || !idx || !dw || !shape_ok(rows, K, N)) return AC_EINVAL;
+    if (!ac_aligned16(ycat) || !ac_aligned16(gamma) || !ac_aligned16(beta) || !ac_aligned16(dpooled) || ((uintptr_t)idx & 3u))
+        return AC_EALIGN;
+    TailParams p = {};
+    p.ycat = ycat; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float *>(mean); p.rstd = const_cast<float *>(rstd);
+    p.dpooled = dpooled; p.idx = const_cast<uint8_t *>(idx); p.dw = dw;
+    p.rows = rows; p.nblocks = (int)(rows / R);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 192) return launch<tail_bwd_dw_kernel<192, 64>>(grid_for(p.nblocks, 2), 256, dw_lds<192, 64>(), p, st);
+    return launch<tail_bwd_dw_kernel<384, 128>>(grid_for(p.nblocks, 1), 512, dw_lds<384, 128>(), p, st);
 }

@@ -2046,19 +2046,21 @@ class _ConvGroup1d(Function):
         ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
         ctx.tail = False
         if pw_w is not None:
-            # LayerNorm + GELU + 1x1 conv + MaxPool(4) in one kernel (ac_tail.hip): the caller checked tail_covered()
+            # LayerNorm + GELU + 1x1 conv + MaxPool(4) behind the conv bank in one kernel (ac_tail.hip): nothing of row
+            # length Ncat is written — z = gelu(LN(ycat)) exists only as (hi, lo) planes of 32 rows in LDS, the backward
+            # pass rebuilds it from ycat.  The caller checked tail_covered().
             rows, Cpw = B * L, pw_w.shape[0]
-            z = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)      # the 1x1 weight gradient reads it
             mean = torch.empty(rows, device=dev, dtype=torch.float32)
             rstd = torch.empty(rows, device=dev, dtype=torch.float32)
             pooled = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.float32)
             pidx = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.uint8)
-            _lib.check(_lib_().ac_ln_gelu_pw_pool_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta), ln_eps, _p(pw_w),
-                                                      _p(pw_b), _p(z), _p(mean), _p(rstd), _p(pooled), _p(pidx), rows,
-                                                      Ncat, Cpw, _stream()), "ac_ln_gelu_pw_pool_fwd")
+            wh, wl = split16_w(pw_w)
+            _lib.check(_lib_().ac_spectail_fwd(_p(ycat), _p(ln_gamma), _p(ln_beta), ln_eps, _p(wh), _p(wl), _p(pw_b),
+                                               _p(mean), _p(rstd), _p(pooled), _p(pidx), rows, Ncat, Cpw, _stream()),
+                       "ac_spectail_fwd")
             _tap("pool4", pidx)
             ctx.tail, ctx.pw = True, (pw_w, pw_b)
-            ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta, z, pidx, pw_w)
+            ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta, pidx, pw_w)
             return pooled
         if ctx.fused_ln:
             rows = B * L
@@ -2106,32 +2108,31 @@ class _ConvGroup1d(Function):
             saved = ctx.saved_tensors
             xpad, ws = saved[0], list(saved[1:1 + nconv])
             ycat, mean, rstd, ln_gamma, ln_beta = saved[1 + nconv:6 + nconv]
+            dpool = pidx = pw_w = None
             if ctx.tail:
-                # gradient of the fused tail with the kernels of the unfused one: un-pool, the 1x1 conv's weight /
-                # bias gradients from (d out, z), and d z = d out . W — the "dycat" LayerNorm's backward takes over
-                z, pidx, pw_w = saved[6 + nconv:]
+                # fused tail (ac_tail.hip): the 1x1 conv's weight gradient = scatter(d pooled)^T . z with z rebuilt from
+                # ycat in the kernel, its bias gradient = column sums of d pooled (every pooled gradient reaches exactly
+                # one row); the (hi, lo) planes of d ycat come from ac_spectail_bwd_dx below, in LayerNorm's place
+                pidx, pw_w = saved[6 + nconv:]
                 Cpw, rows = pw_w.shape[0], B * L
-                dout = torch.empty(B, L, Cpw, device=dev, dtype=torch.float32)
-                _lib.check(_lib_().ac_maxpool4_bwd(_p(dycat), (L // 4) * Cpw, _p(pidx), _p(dout), B, L, Cpw, _stream()),
-                           "ac_maxpool4_bwd")
+                dpool = _chk(dycat, "dpooled")
                 if ctx.needs_input_grad[6]:
                     wsink = _sink(ctx.pw[0])
                     dpw_w = wsink if wsink is not None else torch.zeros(Cpw, Ncat, device=dev, dtype=torch.float32)
-                    gemm(AC_GEMM_TN, Cpw, Ncat, rows, mat(_p(dout), Cpw), mat(_p(z), Ncat), mat(_p(dpw_w), Ncat),
-                         accumulate=2, split_k=_split_for(Cpw, Ncat, rows))
+                    _lib.check(_lib_().ac_spectail_bwd_dw(_p(ycat), _p(mean), _p(rstd), _p(ln_gamma), _p(ln_beta),
+                                                          _p(dpool), _p(pidx), _p(dpw_w), rows, Ncat, Cpw, _stream()),
+                               "ac_spectail_bwd_dw")
                     if wsink is not None:
                         dpw_w = None
                         _grad_written(ctx.pw[0])
                 if ctx.pw[1] is not None and ctx.needs_input_grad[7]:
                     bsink = _sink(ctx.pw[1])
                     if bsink is not None:
-                        _lib.check(_lib_().ac_colsum(_p(dout), Cpw, _p(bsink), rows, Cpw, 1, _stream()), "ac_colsum")
+                        _lib.check(_lib_().ac_colsum(_p(dpool), Cpw, _p(bsink), rows // 4, Cpw, 1, _stream()), "ac_colsum")
                         _grad_written(ctx.pw[1])
                     else:
-                        dpw_b = colsum(_p(dout), Cpw, rows, Cpw, dev)
-                dz = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32)
-                gemm(AC_GEMM_NN, rows, Ncat, Cpw, mat(_p(dout), Cpw), mat(_p(pw_w), Ncat), mat(_p(dz), Ncat))
-                dycat, dy16in = dz, None
+                        dpw_b = colsum(_p(dpool), Cpw, rows // 4, Cpw, dev)
+                dycat, dy16in = None, None
             gsink, bsink = _sink(ctx.params[1]), _sink(ctx.params[2])
             ln_direct = gsink is not None and bsink is not None
             dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
@@ -2175,16 +2176,29 @@ class _ConvGroup1d(Function):
             elif direct16:
                 dyop = torch.empty(B * L, Ncat, device=dev, dtype=_H16)
                 out16 = dyop
+            elif ctx.tail:
+                # (no plane-fed consumer for this call - e.g. an input that needs no gradient: planes, then their sum)
+                both = torch.empty(2, B * L, Ncat, device=dev, dtype=_H16)
+                out16, lo16 = both[0], both[1]
             else:
                 dpre, out16 = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32), None
-            _lib.check(_lib_().ac_layernorm_bwd_split(_p(dy16in if dy16in is not None else dycat), Ncat,
-                                                      _p(ycat), Ncat, _p(mean), _p(rstd),
-                                                      _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
-                                                      _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
-                                                      _p(out16), _p(lo16), Ncat, seg[0], seg[1], seg[2],
-                                                      1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
-                                                      _stream()),
-                       "ac_layernorm_bwd_split")
+            if ctx.tail:
+                wth, wtl = split16_wT(pw_w)
+                _lib.check(_lib_().ac_spectail_bwd_dx(_p(ycat), _p(mean), _p(rstd), _p(ln_gamma), _p(ln_beta), _p(dpool),
+                                                      _p(pidx), _p(wth), _p(wtl), _p(out16), _p(lo16), seg[0], seg[1],
+                                                      seg[2], _p(dgam), _p(dbet), _p(bias_sums), B * L, Ncat,
+                                                      pw_w.shape[0], _stream()), "ac_spectail_bwd_dx")
+                if not (planes1 or planes_direct):
+                    dpre = (both[0].float() + both[1].float()).reshape(B, L, Ncat)
+            else:
+                _lib.check(_lib_().ac_layernorm_bwd_split(_p(dy16in if dy16in is not None else dycat), Ncat,
+                                                          _p(ycat), Ncat, _p(mean), _p(rstd),
+                                                          _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
+                                                          _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
+                                                          _p(out16), _p(lo16), Ncat, seg[0], seg[1], seg[2],
+                                                          1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
+                                                          _stream()),
+                           "ac_layernorm_bwd_split")
             dycat = dpre
             if ln_direct:
                 dgam = dbet = None
@@ -2357,19 +2371,25 @@ class _ConvGroup1d(Function):
         return (dx, None, dgam, dbet, None, None, dpw_w, dpw_b, *grads)
 
 
-# OFF by default — measured and not adopted (profiles/r03_fused_tail_ab.txt): the one-kernel tail is correct (tests/
-# test_gpu_tail.py) but not faster.  It is bound by VALU issue (LayerNorm + GELU + the hi / lo split of every element at
-# two waves per SIMD) and by the serial latency of its statistics prologue, not by HBM: stage 1 (2 097 152 x 192 -> 64)
-# 1.42 ms against 0.72 + 0.54 + 0.13 ms for the three kernels it replaces, and on the wider stages every column tile
-# repeats the normalisation (0.55 - 0.76 ms per launch against 0.2 - 0.6 ms).  Whole step 31.2 vs 30.3 ms.
-_FUSED_TAIL = bool(_os.environ.get("APPLECIDER_FUSED_TAIL"))
+_FUSED_TAIL = True   # tests / A-B: False = LayerNorm, 1x1 conv and MaxPool(4) as separate kernels everywhere
 
 
-def tail_covered(B: int, L: int, Ncat: int, Cpw: int) -> bool:
-    """Whether LayerNorm + GELU + 1x1 conv + MaxPool(4) of a pooled SpectraNetBlock run as ONE forward kernel
-    (ac_ln_gelu_pw_pool_fwd, split-bf16 mode only): 128-row tiles of whole pooling groups, 32-deep K tiles."""
-    return bool(_FUSED_TAIL and x3_mode() and (B * L) % 128 == 0 and L % 4 == 0 and Ncat % 32 == 0
-                and 64 <= Ncat <= 1536 and Cpw % 32 == 0)
+def tail_covered(B: int, L: int, Cin: int, Cout: int, nk: int = 3) -> bool:
+    """Whether LayerNorm + GELU + 1x1 conv + MaxPool(4) of a pooled SpectraNetBlock (spectranet.py:31-40) run as the
+    fused tail kernels behind the conv bank (ac_tail.hip: ac_spectail_fwd / _bwd_dx / _bwd_dw; split-bf16 mode):
+    the kernels' shapes (32-row blocks; (3 Cout, Cout) = (192, 64) or (384, 128): stages 1 and 2 of the default
+    configuration, 75 % of the tails' bytes) AND the bank's gradient products all on the plane-fed kernels, because the
+    backward kernel hands d(conv outputs) over as (hi, lo) planes only."""
+    if not (_FUSED_TAIL and x3_mode() and _LN_PLANES and L % 32 == 0 and nk * Cout % 8 == 0):
+        return False
+    if not _lib_().ac_spectail_supported(B * L, nk * Cout, Cout):
+        return False
+    if Cin == 1:   # the Toeplitz products of stage 1 on the plane-fed kernels (_ConvGroup1d: `toep`, `planes1`)
+        Lq = L // 8
+        toep = Lq % 256 == 0 or (8 <= Lq < 128 and (Lq & (Lq - 1)) == 0 and (B * Lq) % 256 == 0)
+        return bool(_CONVWIN and _CONVWIN_X3_FUSED and _TOEPLITZ_RING and _WGRAD_WIN and Cout % 16 == 0 and L % 8 == 0
+                    and toep and Lq % 64 == 0)
+    return bool(Cin % 8 == 0 and _x3_bank_covered(B, L, Cin, Cout))
 
 
 def conv_group1d(x, ksizes, weights, biases, ln=None, out16_only=False, tail=None):

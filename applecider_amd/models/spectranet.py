@@ -54,9 +54,11 @@ class SpectraNetBlock(nn.Module):
             return H.maxpool4(self.downsample(y)) if self.do_pool else y
         # a pooled block feeds LN+GELU straight into the 1x1 conv: in bf16 mode that hand-over (and
         # the gradient coming back) is bf16 only — the [B, L, 3*Cout] fp32 tensors are never written
-        ncat = len(self.kernel_sizes) * self.convs[0].weight.shape[0]
-        if self.do_pool and H.tail_covered(x.shape[0], x.shape[1], ncat, self.downsample.cout):
-            # split-bf16 mode: LayerNorm + GELU + 1x1 conv + MaxPool(4) are one kernel behind the conv bank
+        cout = self.convs[0].weight.shape[0]
+        if (self.do_pool and self.downsample.cout == cout
+                and H.tail_covered(x.shape[0], x.shape[1], x.shape[2], cout, len(self.kernel_sizes))):
+            # split-bf16 mode: LayerNorm + GELU + 1x1 conv + MaxPool(4) are one kernel behind the conv bank (and two in
+            # the backward pass); nothing as wide as the concatenated channels is written in between
             return H.conv_group1d(x, self.kernel_sizes, [c.weight for c in self.convs], [c.bias for c in self.convs],
                                   ln=(self.norm.weight, self.norm.bias, self.norm.eps),
                                   tail=(self.downsample.weight, self.downsample.bias))

@@ -642,17 +642,34 @@ int ac_fft_taps_inv(const float *m, int32_t Cout, int32_t Cin, int32_t k, int32_
                     float *dw, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Tail of a pooled SpectraNetBlock in one forward kernel (spectranet.py:31-40), split-bf16 arithmetic:
- *     pooled[r / 4, n] = max_{j < 4} ( bias[n] + sum_k gelu(LN(ycat[4 (r/4) + j, :]))[k] * w[n, k] ),   idx = argmax j
- * ycat [rows, K] (row stride ld), gamma / beta [K], w [N, K]; outputs: z [rows, K] = gelu(LN(ycat)) (nullable; the
- * 1x1 conv's weight gradient reads it), mean / rstd [rows] (LayerNorm's backward), pooled [rows / 4, N], idx uint8.
- * rows % 128 == 0 (and the pooling groups are rows 4i .. 4i + 3: L % 4 == 0), K % 32 == 0, 64 <= K <= 1536, ld == K,
- * N % 32 == 0; 16-byte aligned.
- * The backward pass uses ac_maxpool4_bwd, ac_gemm and ac_layernorm_bwd(_split) with these tensors.
+ * Tail of a pooled SpectraNetBlock (spectranet.py:31-40), split-bf16 arithmetic, fused so that nothing of row length
+ * K is written in the forward pass and only the operand planes of d ycat in the backward pass:
+ *     pooled[r / 4, n] = max_{j < 4} ( bias[n] + sum_k gelu(LN(ycat[4 (r/4) + j, :]))[k] * w[n, k] ),  idx = argmax j
+ * ycat [rows, K] contiguous fp32 (rows = B * L, pooling windows = rows 4i .. 4i + 3), gamma / beta [K], w [N, K].
+ * Shapes: ac_spectail_supported(rows, K, N) != 0  <=>  rows % 32 == 0 and (K, N) in {(192, 64), (384, 128)}.
+ * GELU is the erf form through a rational erf (max abs error 4.5e-7).
+ *   ac_spectail_fwd     w_hi / w_lo: (hi, lo) bf16 planes of w [N][K] (ac_split_bf16).  Outputs mean / rstd [rows]
+ *                       (biased variance, eps inside the root), pooled [rows / 4, N], idx uint8 [rows / 4, N] (first
+ *                       maximum wins, NaN propagates: torch.nn.MaxPool1d).
+ *   ac_spectail_bwd_dx  d pooled [rows / 4, N] -> (hi, lo) planes of d ycat [.., K] (row r = (b, l) lands at
+ *                       b * seg_pitch + seg_off + l when seg_len = L > 0, at r otherwise: the zero-padded layout the
+ *                       conv bank's gradient products read; the caller zeroes the pad rows), and ACCUMULATES
+ *                       dgamma / dbeta / dxsum [K] (dxsum = column sums of d ycat = the conv biases' gradient; each
+ *                       nullable).  wt_hi / wt_lo: planes of the TRANSPOSE w^T [K][N] (ac_transpose_split_bf16).
+ *   ac_spectail_bwd_dw  dw [N][K] += scatter(d pooled)^T . gelu(LN(ycat))   (fp32 atomics).
+ * The 1x1 conv's bias gradient is the column sum of d pooled (ac_colsum).
  * ---------------------------------------------------------------------- */
-int ac_ln_gelu_pw_pool_fwd(const float *ycat, int64_t ld, const float *gamma, const float *beta, float eps,
-                           const float *w, const float *bias, float *z, float *mean, float *rstd, float *pooled,
-                           uint8_t *idx, int64_t rows, int32_t K, int32_t N, ac_stream_t stream);
+int ac_spectail_supported(int64_t rows, int32_t K, int32_t N);
+int ac_spectail_fwd(const float *ycat, const float *gamma, const float *beta, float eps, const void *w_hi,
+                    const void *w_lo, const float *bias, float *mean, float *rstd, float *pooled, uint8_t *idx,
+                    int64_t rows, int32_t K, int32_t N, ac_stream_t stream);
+int ac_spectail_bwd_dx(const float *ycat, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                       const float *dpooled, const uint8_t *idx, const void *wt_hi, const void *wt_lo, void *dx_hi,
+                       void *dx_lo, int32_t seg_len, int32_t seg_pitch, int32_t seg_off, float *dgamma, float *dbeta,
+                       float *dxsum, int64_t rows, int32_t K, int32_t N, ac_stream_t stream);
+int ac_spectail_bwd_dw(const float *ycat, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                       const float *dpooled, const uint8_t *idx, float *dw, int64_t rows, int32_t K, int32_t N,
+                       ac_stream_t stream);
 
 #ifdef __cplusplus
 }
