@@ -58,9 +58,9 @@ __device__ __forceinline__ float ac_gelu_grad(float x) {
     return cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
 }
 // Rational erf (odd polynomial / even polynomial on |x| <= 4, the form Eigen and XLA use for
-// float): max abs error 4.5e-7 against the exact function, ~15 FMAs and one division instead of
-// the branchy library routine.  Used by the bf16-mode GEMM epilogues only, where GELU over a
-// 4C-wide hidden layer cost as much as the product itself; the fp32 path keeps erff.
+// float): max abs error 4.5e-7 against the exact function, ~15 FMAs and one reciprocal instead of
+// the branchy library routine.  Used by the bf16-mode GEMM epilogues, where GELU over a 4C-wide hidden layer cost as
+// much as the product itself, and by the fused SpectraNet tail (split-bf16 mode); the exact-fp32 mode keeps erff.
 __device__ __forceinline__ float ac_erf_fast(float x) {
     x = fminf(fmaxf(x, -4.f), 4.f);
     const float x2 = x * x;
@@ -76,7 +76,9 @@ __device__ __forceinline__ float ac_erf_fast(float x) {
     q = fmaf(q, x2, -1.68282697438203e-03f);
     q = fmaf(q, x2, -7.37332916720468e-03f);
     q = fmaf(q, x2, -1.42647390514189e-02f);
-    return x * p * __frcp_rn(q);
+    // v_rcp_f32 (1 ulp), not the correctly rounded quotient: that is a ten-instruction sequence per element, and the
+    // fused SpectraNet tail kernels are bound by VALU issue (non-packed fp32: 4 cycles per wave instruction)
+    return x * p * __builtin_amdgcn_rcpf(q);
 }
 __device__ __forceinline__ float ac_gelu_fast(float x) {
     return 0.5f * x * (1.0f + ac_erf_fast(x * 0.70710678118654752440f));
@@ -91,6 +93,7 @@ __device__ __forceinline__ float ac_sigmoid(float x) { return 1.0f / (1.0f + __e
 __device__ __forceinline__ float ac_act(float v, int kind) {
     switch (kind) {
         case AC_ACT_GELU: return ac_gelu(v);
+        case AC_ACT_GELU_FAST: return ac_gelu_fast(v);
         case AC_ACT_RELU: return v > 0.f ? v : 0.f;
         case AC_ACT_SIGMOID: return ac_sigmoid(v);
         case AC_ACT_TANH: return tanhf(v);
@@ -101,6 +104,7 @@ __device__ __forceinline__ float ac_act(float v, int kind) {
 __device__ __forceinline__ float ac_dact(float aux, int kind) {
     switch (kind) {
         case AC_ACT_GELU: return ac_gelu_grad(aux);
+        case AC_ACT_GELU_FAST: return ac_gelu_grad_fast(aux);
         case AC_ACT_RELU: return aux > 0.f ? 1.f : 0.f;
         case AC_ACT_SIGMOID: return aux * (1.f - aux);
         case AC_ACT_TANH: return 1.f - aux * aux;

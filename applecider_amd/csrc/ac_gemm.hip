@@ -81,13 +81,18 @@ __device__ __forceinline__ int64_t inner_off(const int32_t *goff, int i) {
     return goff ? (int64_t)goff[i >> 5] + (i & 31) : (int64_t)i;
 }
 
+// GELU means the rational-erf form in every math mode but the exact-fp32 one (the compile-time variants: E_FAST)
+__device__ __forceinline__ int eff_act(const ac_gemm_desc &d, int code) {
+    return (code == AC_ACT_GELU && d.math != AC_MATH_F32) ? AC_ACT_GELU_FAST : code;
+}
+
 __device__ __forceinline__ void epilogue_store(const ac_gemm_desc &d, uint64_t dseed, int m, int n, float acc,
                                                int64_t caddr) {
     float v = acc * d.alpha;
     if (d.bias) v += d.bias[n];
     if (d.pre_out) d.pre_out[(int64_t)m * d.ld_pre + n] = v;
-    v = ac_act(v, d.act);
-    if (d.dact) v *= ac_dact(d.aux[(int64_t)m * d.ld_aux + n], d.dact);
+    v = ac_act(v, eff_act(d, d.act));
+    if (d.dact) v *= ac_dact(d.aux[(int64_t)m * d.ld_aux + n], eff_act(d, d.dact));
     if (d.mask16) v = epi_bf16_to_f32(((const unsigned short *)d.mask16)[(int64_t)m * d.ld_mask16 + n]) > 0.f ? v : 0.f;
     if (d.colscale) v *= d.colscale[n];
     if (d.drop_p > 0.f)
@@ -184,12 +189,12 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, uint64_t dse
     if (d.pre_out) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
     if (d.act) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ac_act(v[j], d.act);
+        for (int j = 0; j < 4; ++j) v[j] = ac_act(v[j], eff_act(d, d.act));
     }
     if (d.dact) {
         const f32x4 a = *(const f32x4 *)(d.aux + (int64_t)m * d.ld_aux + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= ac_dact(a[j], d.dact);
+        for (int j = 0; j < 4; ++j) v[j] *= ac_dact(a[j], eff_act(d, d.dact));
     }
     if (d.mask16) {
         const ushort4 k = *(const ushort4 *)((const unsigned short *)d.mask16 + (int64_t)m * d.ld_mask16 + n);
@@ -227,7 +232,7 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, uint64_t dse
 enum : unsigned {
     E_BIAS = 1u, E_PRE = 2u, E_GELU = 4u, E_RELU = 8u, E_DGELU = 16u, E_MASK16 = 32u, E_CSCALE = 64u,
     E_DROP = 128u, E_RES = 256u, E_C16 = 512u, E_C32 = 1024u, E_ACC = 2048u,
-    E_FAST = 4096u,  // bf16 math modes: rational erf inside GELU / GELU'
+    E_FAST = 4096u,  // bf16 / split-bf16 math modes: rational erf inside GELU / GELU'
     E_GOFF = 8192u   // C columns through the offset table (conv outputs scattered into the cat buffer)
 };
 #define AC_EPI_VARIANTS(X)                                                                      \
@@ -240,7 +245,8 @@ enum : unsigned {
     X(16, E_C16 | E_BIAS | E_GELU | E_FAST) X(17, E_C32 | E_BIAS | E_GELU | E_FAST) X(18, E_C16)     \
     X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF) X(21, E_C16 | E_BIAS | E_GOFF)                    \
     X(22, E_C32 | E_BIAS | E_GELU | E_PRE) X(23, E_C32 | E_BIAS | E_RELU)                                 \
-    X(24, E_C32 | E_BIAS | E_RELU | E_PRE | E_RES) X(25, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES)
+    X(24, E_C32 | E_BIAS | E_RELU | E_PRE | E_RES) X(25, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES)       \
+    X(26, E_C32 | E_BIAS | E_GELU | E_PRE | E_FAST) X(27, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES | E_FAST)
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
@@ -1353,10 +1359,10 @@ int epilogue_variant(const ac_gemm_desc &d, int accumulate) {
     unsigned f = d.c.goff ? E_GOFF : 0;
     if (d.bias) f |= E_BIAS;
     if (d.pre_out) f |= E_PRE;
-    if (d.act == AC_ACT_GELU) f |= E_GELU;
+    if (d.act == AC_ACT_GELU || d.act == AC_ACT_GELU_FAST) f |= E_GELU;
     else if (d.act == AC_ACT_RELU) f |= E_RELU;
     else if (d.act != AC_ACT_NONE) return EPI_GENERIC;
-    if (d.dact == AC_ACT_GELU) f |= E_DGELU;
+    if (d.dact == AC_ACT_GELU || d.dact == AC_ACT_GELU_FAST) f |= E_DGELU;
     else if (d.dact != AC_ACT_NONE) return EPI_GENERIC;
     if (d.mask16) f |= E_MASK16;
     if (d.colscale) f |= E_CSCALE;
@@ -1365,7 +1371,10 @@ int epilogue_variant(const ac_gemm_desc &d, int accumulate) {
     if (d.c16) f |= E_C16;
     if (d.c.ptr) f |= E_C32;
     if (accumulate == 1) f |= E_ACC;
-    if ((d.math == AC_MATH_BF16 || d.math == AC_MATH_BF16_IN) && (f & (E_GELU | E_DGELU))) f |= E_FAST;
+    // every mode but the exact-fp32 one takes the rational erf (the backward kernels of a split-bf16 step get
+    // AC_ACT_GELU_FAST from the host, so forward and backward differentiate the same function)
+    if ((d.math != AC_MATH_F32 || d.act == AC_ACT_GELU_FAST || d.dact == AC_ACT_GELU_FAST) && (f & (E_GELU | E_DGELU)))
+        f |= E_FAST;
 #define AC_EPI_FIND(I, F) if (f == (F)) return I;
     AC_EPI_VARIANTS(AC_EPI_FIND)
 #undef AC_EPI_FIND

@@ -59,14 +59,14 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float t = (v[j] - mu) * rs * g[j] + b[j];
-                    o[j] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                    o[j] = act == AC_ACT_GELU ? ac_gelu(t) : (act == AC_ACT_GELU_FAST ? ac_gelu_fast(t) : t);
                 }
                 *(f32x4 *)(yr + c) = o;
             }
         } else {
             for (int c = lane; c < C; c += 64) {
                 float t = (xr[c] - mu) * rs * gamma[c] + beta[c];
-                yr[c] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                yr[c] = act == AC_ACT_GELU ? ac_gelu(t) : (act == AC_ACT_GELU_FAST ? ac_gelu_fast(t) : t);
             }
         }
     }
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_kernel(
             float xh = (xr[c] - mu) * rs;
             float d = dyr[c];
             if (act == AC_ACT_GELU) d *= ac_gelu_grad(xh * gamma[c] + beta[c]);
+                else if (act == AC_ACT_GELU_FAST) d *= ac_gelu_grad_fast(xh * gamma[c] + beta[c]);
             float g = d * gamma[c];
             s1 += g;
             s2 += g * xh;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_kernel(
             float xh = (xr[c] - mu) * rs;
             float d = dyr[c];
             if (act == AC_ACT_GELU) d *= ac_gelu_grad(xh * gamma[c] + beta[c]);
+                else if (act == AC_ACT_GELU_FAST) d *= ac_gelu_grad_fast(xh * gamma[c] + beta[c]);
             float g = d * gamma[c];
             dxr[c] = rs * (g - c1 - xh * c2);
         }
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_reg_kernel(
                     const float h = (xh[j][e] - mu) * rs;
                     float dd = d[j][e];
                     if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                else if (act == AC_ACT_GELU_FAST) dd *= ac_gelu_grad_fast(h * g4[j][e] + b4[j][e]);
                     xh[j][e] = h;
                     d[j][e] = dd;
                     const float g = dd * g4[j][e];
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_reg_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = (v[j][e] - mu) * rs * g4[j][e] + b4[j][e];
-                    o[e] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                    o[e] = act == AC_ACT_GELU ? ac_gelu(t) : (act == AC_ACT_GELU_FAST ? ac_gelu_fast(t) : t);
                 }
                 *(f32x4 *)(y + r * ldy + 4 * lane + 256 * j) = o;
             }
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_fwd_sub_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = (v[j][e] - mu) * rs * g4[j][e] + b4[j][e];
-                o[e] = act == AC_ACT_GELU ? ac_gelu(t) : t;
+                o[e] = act == AC_ACT_GELU ? ac_gelu(t) : (act == AC_ACT_GELU_FAST ? ac_gelu_fast(t) : t);
             }
             if (y) *(f32x4 *)(y + r * ldy + 4 * (sub + G * j)) = o;
             if (y16) {
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_sub_kernel(
                 const float h = (xh[j][e] - mu) * rs;
                 float dd = d[j][e];
                 if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                else if (act == AC_ACT_GELU_FAST) dd *= ac_gelu_grad_fast(h * g4[j][e] + b4[j][e]);
                 xh[j][e] = h;
                 d[j][e] = dd;
                 const float g = dd * g4[j][e];
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void layernorm_bwd_wide_kernel(
                     const float h = (xh[j][e] - mu) * rs;
                     float dd = d[j][e];
                     if (act == AC_ACT_GELU) dd *= ac_gelu_grad(h * g4[j][e] + b4[j][e]);
+                else if (act == AC_ACT_GELU_FAST) dd *= ac_gelu_grad_fast(h * g4[j][e] + b4[j][e]);
                     xh[j][e] = h;
                     d[j][e] = dd;
                     const float g = dd * g4[j][e];
@@ -858,7 +863,7 @@ extern "C" int ac_layernorm_fwd(const float *x, int64_t ldx, const float *gamma,
                                 float *rstd, int64_t rows, int32_t C, float eps, int32_t act,
                                 void *y16, int64_t ldy16, int32_t x_bf16, ac_stream_t stream) {
     if (!x || !gamma || !beta || (!y && !y16) || rows < 0 || C <= 0) return AC_EINVAL;
-    if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
+    if (act != AC_ACT_NONE && act != AC_ACT_GELU && act != AC_ACT_GELU_FAST) return AC_EINVAL;
     if (rows == 0) return AC_OK;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                      (x_bf16 ? (((uintptr_t)x & 7u) == 0) : ac_aligned16(x)) &&
@@ -930,8 +935,8 @@ extern "C" int ac_layernorm_bwd_split(const float *dy, int64_t lddy, const float
     if (dx16_lo && (!dx16 || ((uintptr_t)dx16_lo & 7u))) return AC_EINVAL;
     if (seg_len < 0 || (seg_len > 0 && (rows % seg_len || seg_pitch < seg_len + seg_off || seg_off < 0)))
         return AC_EINVAL;
-    if (act == AC_ACT_GELU && !beta) return AC_EINVAL;
-    if (act != AC_ACT_NONE && act != AC_ACT_GELU) return AC_EINVAL;
+    if ((act == AC_ACT_GELU || act == AC_ACT_GELU_FAST) && !beta) return AC_EINVAL;
+    if (act != AC_ACT_NONE && act != AC_ACT_GELU && act != AC_ACT_GELU_FAST) return AC_EINVAL;
     if (C > 4096) return AC_EINVAL;  // 3*C floats of LDS
     if (rows == 0) return AC_OK;
     hipStream_t stream = (hipStream_t)stream_;

@@ -127,30 +127,39 @@ __device__ __forceinline__ void write_z_planes(const RowRegs<K, TPR> &x, float m
 }
 
 // d(1x1 output) of one block = the pooled gradient scattered to the arg-max row of each window, as (hi, lo) planes
-// [R][DP]: work item (pooled row pr < 8, four channels n4)
-template <int N, int DP, int NT>
-__device__ __forceinline__ void write_dout_planes(const float *dpooled, const uint8_t *idx, int64_t prow0,
-                                                  unsigned short *dhi, unsigned short *dlo, int t) {
-    for (int i = t; i < (R / 4) * (N / 4); i += NT) {
-        const int pr = i / (N / 4), n = 4 * (i - pr * (N / 4));
-        const f32x4 g = ac_gload<f32x4>(dpooled + (prow0 + pr) * N + n);
-        const uchar4 a = *(const uchar4 *)(idx + (prow0 + pr) * N + n);
-        s16x4 hi, lo;
-        split4(g, hi, lo);
-        const unsigned am[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[e] = am[e] == (unsigned)j ? hi[e] : (short)0;
-                l[e] = am[e] == (unsigned)j ? lo[e] : (short)0;
-            }
-            *(s16x4 *)(dhi + (4 * pr + j) * DP + n) = h;
-            *(s16x4 *)(dlo + (4 * pr + j) * DP + n) = l;
+// [R][DP].  Work item (pooled row pr < 8, four channels): at most one per thread (8 N / 4 <= NT); its global loads are
+// issued one block ahead (DoutRegs::load), the LDS stores when the block's turn comes (store).
+template <int N, int DP>
+struct DoutRegs {
+    f32x4 g;
+    unsigned a;
+    __device__ __forceinline__ void load(const float *dpooled, const uint8_t *idx, int64_t prow0, int t) {
+        if (t < (R / 4) * (N / 4)) {
+            const int pr = t / (N / 4), n = 4 * (t - pr * (N / 4));
+            g = ac_gload<f32x4>(dpooled + (prow0 + pr) * N + n);
+            a = ac_gload<unsigned>((const unsigned *)(idx + (prow0 + pr) * N + n));
         }
     }
-}
+    __device__ __forceinline__ void store(unsigned short *dhi, unsigned short *dlo, int t) const {
+        if (t < (R / 4) * (N / 4)) {
+            const int pr = t / (N / 4), n = 4 * (t - pr * (N / 4));
+            s16x4 hi, lo;
+            split4(g, hi, lo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool on = ((a >> (8 * e)) & 0xFFu) == (unsigned)j;
+                    h[e] = on ? hi[e] : (short)0;
+                    l[e] = on ? lo[e] : (short)0;
+                }
+                *(s16x4 *)(dhi + (4 * pr + j) * DP + n) = h;
+                *(s16x4 *)(dlo + (4 * pr + j) * DP + n) = l;
+            }
+        }
+    }
+};
 
 // =====================================================================================================================
 // forward: NT = 64 * 2 * (N / 32) threads; wave w -> output tile (all 32 rows) x (32 channels nt = w % MT), half
@@ -264,16 +273,28 @@ __global__ __launch_bounds__(128 * (N / 32)) void tail_bwd_dw_kernel(TailParams 
     f32x16 acc[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[j] = zero16();
+    static_assert((R / 4) * (N / 4) <= NT, "one d out work item per thread");
     RowRegs<K, TPR> x;
+    DoutRegs<N, DP> dreg;
+    float mu = 0.f, rs = 0.f;
     int blk = blockIdx.x;
-    if (blk < p.nblocks) x.load(p.ycat, (int64_t)blk * R + r, sub);
+    if (blk < p.nblocks) {
+        x.load(p.ycat, (int64_t)blk * R + r, sub);
+        dreg.load(p.dpooled, p.idx, ((int64_t)blk * R) >> 2, t);
+        mu = p.mean[(int64_t)blk * R + r];
+        rs = p.rstd[(int64_t)blk * R + r];
+    }
     __syncthreads();
     for (; blk < p.nblocks; blk += gridDim.x) {
-        const int64_t row0 = (int64_t)blk * R;
-        const float mu = p.mean[row0 + r], rs = p.rstd[row0 + r];
         write_z_planes<K, TPR, ZP>(x, mu, rs, s_gamma, s_beta, zhi, zlo, r, sub);
-        write_dout_planes<N, DP, NT>(p.dpooled, p.idx, row0 >> 2, dhi, dlo, t);
-        if (blk + (int)gridDim.x < p.nblocks) x.load(p.ycat, (int64_t)(blk + gridDim.x) * R + r, sub);
+        dreg.store(dhi, dlo, t);
+        if (blk + (int)gridDim.x < p.nblocks) {
+            const int64_t nrow0 = (int64_t)(blk + gridDim.x) * R;
+            x.load(p.ycat, nrow0 + r, sub);
+            dreg.load(p.dpooled, p.idx, nrow0 >> 2, t);
+            mu = p.mean[nrow0 + r];
+            rs = p.rstd[nrow0 + r];
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < R / 16; ++s) {
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(128 * (N / 32)) void tail_bwd_dw_kernel(TailParams 
 // elements
 // =====================================================================================================================
 template <int K, int N>
-__global__ __launch_bounds__(512) void tail_bwd_dx_kernel(TailParams p) {
+__global__ __launch_bounds__(512, 2) void tail_bwd_dx_kernel(TailParams p) {
     constexpr int TPR = 16, NT = TPR * R, NW = NT / 64, DP = N + 8, ZF = K + 4, KS = N / 16, NV = K / (4 * TPR);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *dz = (float *)smem_raw;                                   // [R][ZF] fp32
@@ -321,14 +342,29 @@ __global__ __launch_bounds__(512) void tail_bwd_dx_kernel(TailParams p) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float invK = 1.0f / (float)K;
+    static_assert((R / 4) * (N / 4) <= NT, "one d out work item per thread");
     RowRegs<K, TPR> x;
+    DoutRegs<N, DP> dreg;
+    float mu_n = 0.f, rs_n = 0.f;
     int blk = blockIdx.x;
-    if (blk < p.nblocks) x.load(p.ycat, (int64_t)blk * R + r, sub);
+    if (blk < p.nblocks) {
+        x.load(p.ycat, (int64_t)blk * R + r, sub);
+        dreg.load(p.dpooled, p.idx, ((int64_t)blk * R) >> 2, t);
+        mu_n = p.mean[(int64_t)blk * R + r];
+        rs_n = p.rstd[(int64_t)blk * R + r];
+    }
     __syncthreads();
     for (; blk < p.nblocks; blk += gridDim.x) {
         const int64_t row0 = (int64_t)blk * R;
-        write_dout_planes<N, DP, NT>(p.dpooled, p.idx, row0 >> 2, dhi, dlo, t);
-        const float mu = p.mean[row0 + r], rs = p.rstd[row0 + r];
+        dreg.store(dhi, dlo, t);
+        const float mu = mu_n, rs = rs_n;
+        const bool more = blk + (int)gridDim.x < p.nblocks;
+        const int64_t nrow0 = (int64_t)(blk + gridDim.x) * R;
+        if (more) {
+            dreg.load(p.dpooled, p.idx, nrow0 >> 2, t);
+            mu_n = p.mean[nrow0 + r];
+            rs_n = p.rstd[nrow0 + r];
+        }
         __syncthreads();
         for (int tile = w; tile < K / 32; tile += NW) {
             // d z tile: reduction over the N output channels; B = planes of w^T [K][N] straight from L2
@@ -381,7 +417,7 @@ __global__ __launch_bounds__(512) void tail_bwd_dx_kernel(TailParams p) {
             *(s16x4 *)(p.dx_hi + rr * K + c) = hi;
             *(s16x4 *)(p.dx_lo + rr * K + c) = lo;
         }
-        if (blk + (int)gridDim.x < p.nblocks) x.load(p.ycat, (int64_t)(blk + gridDim.x) * R + r, sub);
+        if (more) x.load(p.ycat, nrow0 + r, sub);
     }
     // ---- column sums: the 64 / TPR rows of a wave first (shuffles), then LDS, then one atomic per column and workgroup
 #pragma unroll

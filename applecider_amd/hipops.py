@@ -56,6 +56,16 @@ def get_math() -> str:
     return _MODE
 
 
+ACT_GELU_FAST = 5   # AC_ACT_GELU_FAST (include/applecider_hip.h)
+
+
+def _kact(code: int) -> int:
+    """Activation code handed to the row / elementwise kernels: GELU means the rational-erf form in every math mode but
+    the exact-fp32 one (the GEMM epilogues make the same choice from ac_gemm_desc.math), so that a step's forward and
+    backward kernels differentiate one function."""
+    return ACT_GELU_FAST if (code == ACT_GELU and _MATH != _lib.MATH_F32) else code
+
+
 def _no_f16_backward():
     if _MODE == "f16":
         raise RuntimeError("math mode 'f16' is inference only (fp16 gradients underflow): train in "
@@ -751,13 +761,13 @@ class _Linear(Function):
                 if tgt is None:
                     tgt = db_tmp = torch.zeros(N, device=dy.device, dtype=torch.float32)
                 _lib.check(_lib_().ac_act_bwd_colsum(_p(dy2), _p(aux) if ctx.act != ACT_NONE else None, _p(g), N,
-                                                     _p(tgt), M, N, ctx.act, 1, ctx.drop_p, ctx.drop_seed,
+                                                     _p(tgt), M, N, _kact(ctx.act), 1, ctx.drop_p, ctx.drop_seed,
                                                      _p(_STEP_DEV), _stream()), "ac_act_bwd_colsum")
                 if bsink is not None:
                     _grad_written(ctx.bp)
                 bias_done = True
             else:
-                _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, ctx.act, _stream()),
+                _lib.check(_lib_().ac_act_bwd(_p(dy2), _p(aux), _p(g), M * N, _kact(ctx.act), _stream()),
                            "ac_act_bwd")
         dx = dw = None
         db = db_tmp if (db_tmp is not None and ctx.has_b and ctx.needs_input_grad[2]) else None
@@ -998,7 +1008,7 @@ class _LayerNorm(Function):
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         y16 = _side16_alloc(x.shape, Cn, x.device)
         _lib.check(_lib_().ac_layernorm_fwd(_p(x), Cn, _p(gamma), _p(beta), _p(y), Cn, _p(mean),
-                                            _p(rstd), rows, Cn, eps, act, _p(y16), Cn, 0, _stream()),
+                                            _p(rstd), rows, Cn, eps, _kact(act), _p(y16), Cn, 0, _stream()),
                    "ac_layernorm_fwd")
         if y16 is not None:
             y._ac16 = y16   # the matrix product that consumes y reads this instead of casting
@@ -1021,7 +1031,7 @@ class _LayerNorm(Function):
         db = bs if both else torch.zeros_like(beta)
         _lib.check(_lib_().ac_layernorm_bwd(_p(dy), Cn, _p(x), Cn, _p(mean), _p(rstd), _p(gamma),
                                             _p(beta), _p(dx), Cn, _p(dg), _p(db), None, rows, Cn,
-                                            ctx.act, None, 0, 0, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
+                                            _kact(ctx.act), None, 0, 0, 0, 0, 0, 0, _stream()), "ac_layernorm_bwd")
         if both:
             _grad_written(ctx.gp)
             _grad_written(ctx.bp)
@@ -2071,7 +2081,7 @@ class _ConvGroup1d(Function):
             only16 = out16_only and y16 is not None   # the consumer reads the bf16 copy: skip fp32
             _lib.check(_lib_().ac_layernorm_fwd(_p(ycat), Ncat, _p(ln_gamma), _p(ln_beta),
                                                 None if only16 else _p(y), Ncat,
-                                                _p(mean), _p(rstd), rows, Ncat, ln_eps, ACT_GELU,
+                                                _p(mean), _p(rstd), rows, Ncat, ln_eps, _kact(ACT_GELU),
                                                 _p(y16), Ncat, 1 if cat16 else 0, _stream()),
                        "ac_layernorm_fwd")
             if only16:
@@ -2194,7 +2204,7 @@ class _ConvGroup1d(Function):
                 _lib.check(_lib_().ac_layernorm_bwd_split(_p(dy16in if dy16in is not None else dycat), Ncat,
                                                           _p(ycat), Ncat, _p(mean), _p(rstd),
                                                           _p(ln_gamma), _p(ln_beta), _p(dpre), Ncat, _p(dgam),
-                                                          _p(dbet), _p(bias_sums), B * L, Ncat, ACT_GELU,
+                                                          _p(dbet), _p(bias_sums), B * L, Ncat, _kact(ACT_GELU),
                                                           _p(out16), _p(lo16), Ncat, seg[0], seg[1], seg[2],
                                                           1 if dy16in is not None else 0, 1 if ctx.cat16 else 0,
                                                           _stream()),

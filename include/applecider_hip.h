@@ -81,7 +81,12 @@ const char *ac_strerror(int code);
  * (Time2Vec.py:96-101 feed-forward: linear2(dropout(relu(linear1(x))))).
  * ---------------------------------------------------------------------- */
 enum { AC_GEMM_NT = 0, AC_GEMM_NN = 1, AC_GEMM_TN = 2 };
-enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC_ACT_TANH = 4 };
+enum { AC_ACT_NONE = 0, AC_ACT_GELU = 1, AC_ACT_RELU = 2, AC_ACT_SIGMOID = 3, AC_ACT_TANH = 4,
+       /* erf-form GELU through a rational erf (max abs error 4.5e-7) instead of the library erff: what the split-bf16
+          and bf16 math modes use (their products carry 2^-16 / 2^-8 of rounding; the library routine is 2-3x the VALU
+          instructions, and the row / epilogue kernels around a GELU are bound by VALU issue).  Accepted wherever
+          AC_ACT_GELU is; GEMM epilogues choose it by ac_gemm_desc.math. */
+       AC_ACT_GELU_FAST = 5 };
 /* dact: derivative taken from aux.  GELU/RELU expect the PRE-activation in aux,
  * SIGMOID/TANH expect the activation OUTPUT in aux. */
 /* MFMA input type.  F32 / BF16: operands are fp32 in memory (BF16 rounds them while staging).

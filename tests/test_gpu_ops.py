@@ -998,3 +998,45 @@ def test_linear_small_grid_split_k(dev, mode, M, K, N, scale_res):
             close(a, w_, tol=5e-5, name=f"split vs fp64 [{i}]")
     finally:
         H.set_math("f32")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_gelu_through_rational_erf_outside_exact_mode(dev, mode):
+    """AC_ACT_GELU_FAST (round 4): LayerNorm + GELU, Linear + GELU (epilogue, act' / bias-gradient pass) use the rational
+    erf in every mode but the exact one - forward and backward of the same function, within 2e-6 of torch's erf GELU
+    beyond the product's own rounding; the exact mode keeps the library erf (<= 5e-7)."""
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    try:
+        assert H._kact(H.ACT_GELU) == (H.ACT_GELU if mode == "f32" else H.ACT_GELU_FAST)
+        rows, C = 3000, 384
+        x = (g(dev, rows, C, seed=1) * 2 + 0.5).requires_grad_()
+        w = (1 + 0.1 * g(dev, C, seed=2)).requires_grad_()
+        b = (0.1 * g(dev, C, seed=3)).requires_grad_()
+        go = g(dev, rows, C, seed=4)
+        x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, w, b))
+        y64 = F.gelu(F.layer_norm(x64, (C,), w64, b64, 1e-6))
+        y64.backward(go.double())
+        xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+        yd = H.layer_norm(xd, wd, bd, 1e-6, act="gelu")
+        yd.backward(go.to(dev))
+        tol = 1e-6 if mode == "f32" else 3e-6
+        close(yd, y64, tol=tol, name="ln+gelu y")
+        close(xd.grad, x64.grad, tol=2 * tol, name="ln+gelu dx")
+        close(wd.grad, w64.grad, tol=2 * tol, name="ln+gelu dgamma")
+        # Linear + GELU: the epilogue and the act' pass
+        M, K, N = 2048, 96, 384
+        a, wl, bl, gl = g(dev, M, K, seed=5), g(dev, N, K, seed=6) / math.sqrt(K), g(dev, N, seed=7), g(dev, M, N, seed=8)
+        a64, wl64, bl64 = (t.double().requires_grad_() for t in (a, wl, bl))
+        z64 = F.gelu(a64 @ wl64.t() + bl64)
+        z64.backward(gl.double())
+        ad, wld, bld = (t.clone().to(dev).requires_grad_() for t in (a, wl, bl))
+        zd = H.linear(ad, wld, bld, act="gelu")
+        zd.backward(gl.to(dev))
+        ptol = 2e-6 if mode == "f32" else 3e-5       # the product itself in split-bf16 mode
+        close(zd, z64, tol=ptol, name="linear+gelu")
+        close(ad.grad, a64.grad, tol=2 * ptol, name="linear+gelu dx")
+        close(wld.grad, wl64.grad, tol=2 * ptol, name="linear+gelu dw")
+        close(bld.grad, bl64.grad, tol=2 * ptol, name="linear+gelu db")
+    finally:
+        H.set_math("f32")
