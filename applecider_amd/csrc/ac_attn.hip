@@ -140,10 +140,13 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
     unsigned short *Kh = smh, *Vh = Kh + Tp * 16;
     unsigned short *Kl = Vh + Tp * 16, *Vl = Kl + (SPLIT ? Tp * 16 : 0);
     uint8_t *vm8 = (uint8_t *)(smh + (SPLIT ? 4 : 2) * Tp * 16);
+    unsigned *wk_s = (unsigned *)(vm8 + Tp);                 // dropout: per-key words (ac_att_word)
     const int wg = xcd_order(blockIdx.x, gridDim.x);
     const int b = wg / H, h = wg % H, D = H * 16;
     const float *base = qkv + (int64_t)b * T * 3 * D + h * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    const uint64_t tb = ((uint64_t)b * H + h) * T;
+    const unsigned thr = ac_att_threshold(p_drop);
 
     for (int i = t; i < Tp * 4; i += ATT_NT_FWD) {
         const int tok = i >> 2, c = i & 3;
@@ -155,7 +158,10 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
         img_store4<SPLIT>(Kh, Kl, tok, c, kv);
         img_store4<SPLIT>(Vh, Vl, tok, c, vv);
     }
-    for (int i = t; i < Tp; i += ATT_NT_FWD) vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
+    for (int i = t; i < Tp; i += ATT_NT_FWD) {
+        vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
+        if (DROP) wk_s[i] = ac_att_word(seed, tb + i, 1);
+    }
     __syncthreads();
 
     const float inv_keep = 1.0f / (1.0f - p_drop);
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                qv[j] = a[j] * 0.25f;      // 1/sqrt(d_head), exact
-                qv[4 + j] = c[j] * 0.25f;
+                qv[j] = a[j] * (0.25f * 1.4426950408889634f);      // log2(e) / sqrt(d_head): scores in the log2 domain,
+                qv[4 + j] = c[j] * (0.25f * 1.4426950408889634f);  // so that every exponential is a bare v_exp_f32
             }
         }
         bf16x8 qh, ql;
@@ -208,12 +214,12 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
             }
             const float mn = fmaxf(m, bm);
             const float mref = (mn == -INFINITY) ? 0.f : mn;
-            float acc = l * __expf(m - mref);
+            float acc = l * exp2f(m - mref);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (kb * 32 + 8 * g < T) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc += __expf(sv[4 * g + e] - mref);
+                    for (int e = 0; e < 4; ++e) acc += exp2f(sv[4 * g + e] - mref);
                 }
             l = acc;
             m = mn;
@@ -222,15 +228,15 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
             const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
             const float mn = fmaxf(m, mo);
             const float mref = (mn == -INFINITY) ? 0.f : mn;
-            l = l * __expf(m - mref) + lo * __expf(mo - mref);
+            l = l * exp2f(m - mref) + lo * exp2f(mo - mref);
             m = mref;
         }
-        const float lse_q = m + __logf(l);
-        if (lh == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = lse_q;
+        const float lse_q = m + __log2f(l);                                   // log2-sum-exp2 of the scaled scores
+        if (lh == 0 && q < T) lse[((int64_t)b * H + h) * T + q] = lse_q * 0.6931471805599453f;   // natural units
 
         // ---- pass 2: O = dropout(exp(S - lse)) . V
         f32x16 O = zero16();
-        const uint64_t rbase = (((uint64_t)b * H + h) * T + (uint64_t)q) * T;
+        const unsigned wq = DROP ? ac_att_word(seed, tb + q, 0) : 0u;
         for (int kb = 0; kb < NB; ++kb) {
             const f32x16 S = scores(kb);
             float pv[16];
@@ -239,10 +245,13 @@ __global__ __launch_bounds__(ATT_NT_FWD) void mha_fwd_mfma_kernel(const float *_
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
                 if (kb * 32 + 8 * g < T) {
                     const unsigned w = *(const unsigned *)(vm8 + key0);
+                    uint4 wk4 = {0u, 0u, 0u, 0u};
+                    if (DROP) wk4 = *(const uint4 *)(wk_s + key0);
+                    const unsigned wk[4] = {wk4.x, wk4.y, wk4.z, wk4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
-                        if (DROP) p = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? p * inv_keep : 0.f;
+                        float p = ((w >> (8 * e)) & 0xFFu) ? exp2f(S[4 * g + e] - lse_q) : 0.f;
+                        if (DROP) p = ac_att_keep(wq, wk[e], thr) ? p * inv_keep : 0.f;
                         pv[4 * g + e] = p;
                     }
                 } else {
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     float *lse_s = (float *)(smh + (SPLIT ? 8 : 4) * IMG);
     float *D_s = lse_s + Tp;
     uint8_t *vm8 = (uint8_t *)(D_s + Tp);
+    unsigned *wq_s = (unsigned *)(vm8 + Tp), *wk_s = wq_s + Tp;   // dropout: per-query / per-key words (ac_att_word)
     const int wg = xcd_order(blockIdx.x, gridDim.x);
     const int b = wg / H, h = wg % H, D = H * 16;
     const float *base = qkv + (int64_t)b * T * 3 * D + h * 16;
@@ -320,9 +330,14 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
     for (int i = t; i < Tp; i += ATT_NT_BWD) {
         vm8[i] = (i < T && !(pad && pad[(int64_t)b * T + i])) ? 1 : 0;
         lse_s[i] = i < T ? lse[bh * T + i] : 1e30f;    // rows past T: exp(S - 1e30) = 0
+        if (DROP) {
+            wq_s[i] = ac_att_word(seed, bh * T + i, 0);
+            wk_s[i] = ac_att_word(seed, bh * T + i, 1);
+        }
     }
     __syncthreads();
     const float inv_keep = 1.0f / (1.0f - p_drop);
+    const unsigned thr = ac_att_threshold(p_drop);
 
     // ---- phase A: queries on the lanes -> dQ^T[d, query] = K^T . dS^T
     for (int qb = wave; qb < NB; qb += ATT_NT_BWD / 64) {
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
             gl = row_frag(Gl, q, lh);
         }
         const float lse_q = lse_s[q], D_q = D_s[q];
-        const uint64_t rbase = (bh * T + (uint64_t)q) * T;
+        const unsigned wq = DROP ? wq_s[q] : 0u;
         f32x16 dQ = zero16();
         for (int kb = 0; kb < NB; ++kb) {
             const int krow = kb * 32 + li;
@@ -352,11 +367,14 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
                 const int key0 = kb * 32 + 8 * g + 4 * lh;
                 if (kb * 32 + 8 * g < T) {
                     const unsigned w = *(const unsigned *)(vm8 + key0);
+                    uint4 wk4 = {0u, 0u, 0u, 0u};
+                    if (DROP) wk4 = *(const uint4 *)(wk_s + key0);
+                    const unsigned wk[4] = {wk4.x, wk4.y, wk4.z, wk4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float p = ((w >> (8 * e)) & 0xFFu) ? __expf(S[4 * g + e] - lse_q) : 0.f;
                         float ks = 1.f;
-                        if (DROP) ks = ac_rand01(seed, rbase + (uint64_t)(key0 + e)) >= p_drop ? inv_keep : 0.f;
+                        if (DROP) ks = ac_att_keep(wq, wk[e], thr) ? inv_keep : 0.f;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - D_q);
                     }
                 } else {
@@ -396,6 +414,7 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
             vl = row_frag(Vl, key, lh);
         }
         const bool kvalid = vm8[key] != 0;
+        const unsigned wkk = DROP ? wk_s[key] : 0u;
         f32x16 dV = zero16(), dK = zero16();
         for (int qb = 0; qb < NB; ++qb) {
             const int qrow = qb * 32 + li;
@@ -413,13 +432,14 @@ __global__ __launch_bounds__(ATT_NT_BWD) void mha_bwd_mfma_kernel(
                 const int q0 = qb * 32 + 8 * g + 4 * lh;
                 if (qb * 32 + 8 * g < T) {
                     const f32x4 l4 = *(const f32x4 *)(lse_s + q0), d4 = *(const f32x4 *)(D_s + q0);
+                    uint4 wq4 = {0u, 0u, 0u, 0u};
+                    if (DROP) wq4 = *(const uint4 *)(wq_s + q0);
+                    const unsigned wqv[4] = {wq4.x, wq4.y, wq4.z, wq4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float p = kvalid ? __expf(S[4 * g + e] - l4[e]) : 0.f;
                         float ks = 1.f;
-                        if (DROP)
-                            ks = ac_rand01(seed, (bh * T + (uint64_t)(q0 + e)) * T + (uint64_t)key) >= p_drop
-                                     ? inv_keep : 0.f;
+                        if (DROP) ks = ac_att_keep(wqv[e], wkk, thr) ? inv_keep : 0.f;
                         pt[4 * g + e] = p * ks;
                         ds[4 * g + e] = p * (ks * dP[4 * g + e] - d4[e]);
                     }
@@ -467,7 +487,7 @@ template <bool SPLIT, bool DROP>
 int launch_fwd(const float *qkv, const uint8_t *pad, float *out, float *lse, int B, int T, int H, float p,
                uint64_t seed, const uint64_t *step, hipStream_t st) {
     const int Tp = (T + 31) & ~31;
-    const size_t lds = (size_t)(SPLIT ? 4 : 2) * Tp * 32 + Tp;
+    const size_t lds = (size_t)(SPLIT ? 4 : 2) * Tp * 32 + Tp + (size_t)Tp * sizeof(unsigned);   // + the key words
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_fwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;
@@ -482,7 +502,7 @@ int launch_bwd(const float *dout, const float *qkv, const uint8_t *pad, const fl
                float *dqkv, int B, int T, int H, float p, uint64_t seed, const uint64_t *step,
                hipStream_t st) {
     const int Tp = (T + 31) & ~31;
-    const size_t lds = (size_t)(SPLIT ? 8 : 4) * Tp * 32 + 2 * Tp * sizeof(float) + Tp;
+    const size_t lds = (size_t)(SPLIT ? 8 : 4) * Tp * 32 + 2 * Tp * sizeof(float) + Tp + (size_t)2 * Tp * sizeof(unsigned);
     static const hipError_t attr = hipFuncSetAttribute((const void *)mha_bwd_mfma_kernel<SPLIT, DROP>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     if (attr != hipSuccess) return -(int)attr - 2000;

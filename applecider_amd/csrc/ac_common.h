@@ -142,6 +142,29 @@ __device__ __forceinline__ float ac_rand01(uint64_t seed, uint64_t idx) {
     return (float)(ac_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
 
+// Dropout on ATTENTION WEIGHTS (nn.MultiheadAttention's dropout, HyraxBaselineCLS.py:24-31): the keep / drop decision
+// of (query row, key) is one mixing round over the XOR of two per-token words,
+//     keep  <=>  mix(word_q ^ word_k) >= p * 2^32,
+// word_q = ac_att_word(seed, (b H + h) T + q, 0), word_k = ac_att_word(seed, (b H + h) T + k, 1): a kernel computes
+// the words once per token (T per workgroup, kept on the lane or in a small LDS table) and pays ONE 32-bit multiply
+// per score element instead of the three of ac_hash32 plus its 64-bit index arithmetic - the attention kernels are
+// bound by VALU issue and drew 2-3 masks per element and step (forward, two backward phases).  Bernoulli(1 - p) to
+// 2^-32; the scalar kernels of ac_seq.hip and the matrix-core kernels of ac_attn.hip draw identical masks.
+__device__ __forceinline__ unsigned ac_att_word(uint64_t seed, uint64_t token, unsigned is_key) {
+    return ac_hash32(seed + (is_key ? 0x9E3779B97F4A7C15ull : 0ull), token);
+}
+__device__ __forceinline__ unsigned ac_att_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+__device__ __forceinline__ bool ac_att_keep(unsigned word_q, unsigned word_k, unsigned thr) {
+    unsigned h = word_q ^ word_k;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h >= thr;
+}
+
 // Device-resident step counter: every entry point that draws random numbers takes an optional
 // `step` pointer (uint64 in HBM) and mixes step[0] into the seed its launch was given, so a captured
 // hipGraph of a whole training step draws a new mask at every replay (the host-side seed baked into

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
             o[d] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
-        const uint64_t rbase = (((uint64_t)b * H + h) * T + i) * T;
+        const uint64_t tb = ((uint64_t)b * H + h) * T;
+        const unsigned thr = ac_att_threshold(p_drop), wq = ac_att_word(seed, tb + i, 0);
         for (int j = 0; j < T; ++j) {
             if (msk[j] != 0.f) continue;
             float s = 0.f;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float *__restrict__ 
             const float corr = __expf(m - mn);
             float pj = __expf(s - mn);
             l = l * corr + pj;
-            if (p_drop > 0.f) pj = ac_rand01(seed, rbase + j) >= p_drop ? pj * inv_keep : 0.f;
+            if (p_drop > 0.f) pj = ac_att_keep(wq, ac_att_word(seed, tb + j, 1), thr) ? pj * inv_keep : 0.f;
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = fmaf(pj, Vs[j * DH + d], o[d] * corr);
             m = mn;
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(
                 dp = fmaf(g[d], T1[j * DH + d], dp);
             }
             const float p = __expf(s - li);
-            if (p_drop > 0.f) dp = ac_rand01(seed, (rb + i) * T + j) >= p_drop ? dp * inv_keep : 0.f;
+            if (p_drop > 0.f)
+                dp = ac_att_keep(ac_att_word(seed, rb + i, 0), ac_att_word(seed, rb + j, 1), ac_att_threshold(p_drop))
+                         ? dp * inv_keep : 0.f;
             const float ds = p * (dp - Di);
 #pragma unroll
             for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, T0[j * DH + d], dq[d]);
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(
                 }
                 const float p = __expf(s - lses[i]);
                 float keep = 1.f;
-                if (p_drop > 0.f) keep = ac_rand01(seed, (rb + i) * T + j) >= p_drop ? inv_keep : 0.f;
+                if (p_drop > 0.f)
+                    keep = ac_att_keep(ac_att_word(seed, rb + i, 0), ac_att_word(seed, rb + j, 1),
+                                       ac_att_threshold(p_drop)) ? inv_keep : 0.f;
                 const float pk = p * keep;
                 const float ds = p * (keep * dp - Dv[i]);
 #pragma unroll
