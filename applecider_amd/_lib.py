@@ -134,6 +134,7 @@ SIGNATURES = {
     "ac_dwconv7x7_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_dwconv7x7_fwd_v": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_dwconv7x7_bwd_v": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "ac_dwconv7x7_bwd_res": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ac_avgpool_fwd": [_P, _P, _I32, _I32, _I32, _P],
     "ac_avgpool_bwd": [_P, _P, _I32, _I32, _I32, _P],
     "ac_maxpool4_fwd": [_P, _P, _I64, _P, _I32, _I32, _I32, _P],
@@ -175,6 +176,7 @@ SIGNATURES = {
     "ac_ceil_copy": [_P, _P, _I64, _P],
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_gemm_batched": [C.POINTER(GemmDesc), _I32, _I64, _I64, _I64, _P],
+    "ac_add_segments": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "ac_spectail_supported": [_I64, _I32, _I32],
     "ac_spectail_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
     "ac_spectail_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _I32, _I32, _P],

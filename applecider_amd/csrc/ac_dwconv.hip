@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
                                                             float *__restrict__ dx,
                                                             float *__restrict__ dw,
                                                             float *__restrict__ dbias, int B, int H,
-                                                            int W, int C) {
+                                                            int W, int C, const float *__restrict__ dres) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
     const Geo g = make_geo<XS, WC>(H, W, C);
     const int HW = g.H * g.W;
@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256) void dwconv7x7_bwd_kernel(const float *__restr
                 conv_rows<XS, true>(plane + (py * g.Wp + x0) * CG + c, g.Wp, wt, out);
 #pragma unroll
                 for (int o = 0; o < XS; ++o)
-                    if (x0 + o < W) dxb[(int64_t)(py * W + x0 + o) * C + cglob] = out[o];
+                    if (x0 + o < W) {
+                        const int64_t off = (int64_t)(py * W + x0 + o) * C + cglob;
+                        dxb[off] = dres ? out[o] + dres[(int64_t)b * HW * C + off] : out[o];
+                    }
             }
         }
         __syncthreads();
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(256) void dwconv_rows_bwd_kernel(const float *__res
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ w,
                                                               float *__restrict__ dx, float *__restrict__ dw,
-                                                              float *__restrict__ dbias, int B, int C) {
+                                                              float *__restrict__ dbias, int B, int C,
+                                                              const float *__restrict__ dres) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
     constexpr int HW = W * W;
     float *pdy = plane, *px = plane + HW * CG;
@@ -413,7 +417,10 @@ __global__ __launch_bounds__(256) void dwconv_rows_bwd_kernel(const float *__res
                     }
                 }
 #pragma unroll
-                for (int o = 0; o < W; ++o) dxb[(int64_t)(py * W + o) * C] = out[o];
+                for (int o = 0; o < W; ++o) {
+                    const int64_t off = (int64_t)(py * W + o) * C;
+                    dxb[off] = dres ? out[o] + dres[(int64_t)b * HW * C + cglob + off] : out[o];
+                }
             }
         }
     }
@@ -603,7 +610,7 @@ int launch_pipe_fwd(const float *x, const float *w, const float *bias, float *y,
 template <int W, int SLOTS>
 __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ dx,
-    float *__restrict__ dw, float *__restrict__ dbias, int B, int C, int ncg) {
+    float *__restrict__ dw, float *__restrict__ dbias, int B, int C, int ncg, const float *__restrict__ dres) {
     extern __shared__ __attribute__((aligned(16))) float plane[];
     static_assert(SLOTS >= W && (SLOTS == 8 || SLOTS == 16), "one output row per thread; 8 tap-row slots per half");
     constexpr int HW = W * W, PL = PipeGeo<W>::PLANE, NWV = SLOTS / 2;
@@ -644,6 +651,18 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
             dma_plane<W>(nb + PL, x + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
         }
         const float *pdy = plane + cur * 2 * PL + c, *px = pdy + PL;
+        // the shortcut's gradient of this row (ConvNeXt block: d x = depthwise backward + d shortcut): loaded now,
+        // behind the next planes' DMA and ahead of the row's arithmetic, added when the row is stored.  The counted
+        // wait below still leaves exactly this item's W stores in flight.
+        float rres[W];
+        if (dres) {
+            const float *rp = dres + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
+#pragma unroll
+            for (int o = 0; o < W; ++o) rres[o] = ac_gload<float>(rp + (int64_t)o * C);
+        } else {
+#pragma unroll
+            for (int o = 0; o < W; ++o) rres[o] = 0.f;
+        }
         // ---- phase A: dx row
         {
             float out[W];
@@ -667,7 +686,7 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
             float *dxp = dx + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
 #pragma unroll
             for (int o = 0; o < W; ++o) {   // W stores in every wave (a slot without a row repeats the last row)
-                *dxp = out[o];
+                *dxp = out[o] + rres[o];
                 dxp += C;
             }
         }
@@ -724,7 +743,7 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
 
 template <int W, int SLOTS>
 int launch_pipe_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias, int B, int C,
-                    hipStream_t stream) {
+                    hipStream_t stream, const float *dres) {
     const int ncg = C / CG;
     const size_t planes = (size_t)4 * PipeGeo<W>::PLANE * sizeof(float), red = (size_t)SLOTS * 8 * CG * sizeof(float);
     const size_t lds = planes > red ? planes : red;
@@ -745,7 +764,7 @@ int launch_pipe_bwd(const float *dy, const float *x, const float *w, float *dx, 
         configured = true;
     }
     hipLaunchKernelGGL((dwconv_pipe_bwd_kernel<W, SLOTS>), dim3(wgs), dim3(32 * SLOTS), lds, stream, dy, x, w, dx, dw,
-                       dbias, B, C, ncg);
+                       dbias, B, C, ncg, dres);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -759,11 +778,11 @@ int launch_rows_fwd(const float *x, const float *w, const float *bias, float *y,
 }
 template <int W>
 int launch_rows_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias, int B,
-                    int C, hipStream_t stream) {
+                    int C, hipStream_t stream, const float *dres) {
     const size_t planes = (size_t)2 * W * W * CG * sizeof(float), red = (size_t)8 * 50 * CG * sizeof(float);
     const size_t lds = planes > red ? planes : red;
     hipLaunchKernelGGL(dwconv_rows_bwd_kernel<W>, dim3((B + SPB - 1) / SPB, (C + CG - 1) / CG), dim3(256), lds,
-                       stream, dy, x, w, dx, dw, dbias, B, C);
+                       stream, dy, x, w, dx, dw, dbias, B, C, dres);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -817,7 +836,7 @@ __global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__re
                                                                float *__restrict__ dx,
                                                                float *__restrict__ dw,
                                                                float *__restrict__ dbias, int B,
-                                                               int C, int spb) {
+                                                               int C, int spb, const float *__restrict__ dres) {
     constexpr int P = S * S, T = 2 * S - 1;
     __shared__ float red[SM_SLOTS][T * T + 1][64];
     const int cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__re
                     a = fmaf(d[o], wt[ty * T + tx], a);
                     dwa[ty * T + tx] = fmaf(d[o], xi[i], dwa[ty * T + tx]);
                 }
-                dx[((int64_t)b * P + i) * C + c] = a;
+                dx[((int64_t)b * P + i) * C + c] = dres ? a + dres[((int64_t)b * P + i) * C + c] : a;
             }
         }
     }
@@ -893,7 +912,7 @@ int launch_fwd(const float *x, const float *w, const float *bias, float *y, int 
 }
 template <int XS, int WC = 0>
 int launch_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias,
-               int B, int H, int W, int C, hipStream_t stream) {
+               int B, int H, int W, int C, hipStream_t stream, const float *dres) {
     const Geo g = make_geo<XS, WC>(H, W, C);
     const size_t planes = (size_t)g.np * CG * sizeof(float);
     const size_t red = (size_t)8 * 50 * CG * sizeof(float);
@@ -902,10 +921,10 @@ int launch_bwd(const float *dy, const float *x, const float *w, float *dx, float
     const dim3 grid((B + SPB - 1) / SPB, (C + CG - 1) / CG);
     if (WC > 0 && C % 4 == 0 && ac_aligned16(x) && ac_aligned16(dy))
         hipLaunchKernelGGL((dwconv7x7_bwd_kernel<XS, WC, true>), grid, dim3(256), lds, stream, dy, x, w, dx, dw,
-                           dbias, B, H, W, C);
+                           dbias, B, H, W, C, dres);
     else
         hipLaunchKernelGGL((dwconv7x7_bwd_kernel<XS, WC, false>), grid, dim3(256), lds, stream, dy, x, w, dx, dw,
-                           dbias, B, H, W, C);
+                           dbias, B, H, W, C, dres);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -952,35 +971,41 @@ extern "C" int ac_dwconv7x7_fwd(const float *x, const float *w, const float *bia
 extern "C" int ac_dwconv7x7_bwd(const float *dy, const float *x, const float *w, float *dx,
                                 float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
                                 int32_t C, ac_stream_t stream_) {
-    return ac_dwconv7x7_bwd_v(dy, x, w, dx, dw, dbias, B, H, W, C, 0, stream_);
+    return ac_dwconv7x7_bwd_res(dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, 0, stream_);
 }
 
 extern "C" int ac_dwconv7x7_bwd_v(const float *dy, const float *x, const float *w, float *dx,
                                   float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
                                   int32_t C, int32_t variant, ac_stream_t stream_) {
+    return ac_dwconv7x7_bwd_res(dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, variant, stream_);
+}
+
+extern "C" int ac_dwconv7x7_bwd_res(const float *dy, const float *x, const float *w, const float *dres, float *dx,
+                                    float *dw, float *dbias, int32_t B, int32_t H, int32_t W,
+                                    int32_t C, int32_t variant, ac_stream_t stream_) {
     if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return AC_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     if (variant != 1 && H == W && (W == 15 || W == 7) && C % CG == 0 && ac_aligned16(x) && ac_aligned16(dy) &&
         B * (C / CG) >= 256)
-        return W == 15 ? launch_pipe_bwd<15, 16>(dy, x, w, dx, dw, dbias, B, C, stream)
-                       : launch_pipe_bwd<7, 8>(dy, x, w, dx, dw, dbias, B, C, stream);
+        return W == 15 ? launch_pipe_bwd<15, 16>(dy, x, w, dx, dw, dbias, B, C, stream, dres)
+                       : launch_pipe_bwd<7, 8>(dy, x, w, dx, dw, dbias, B, C, stream, dres);
     if (H == W && (W == 1 || W == 3)) {
         const int spb = small_spb(B);
         dim3 grid((C + 63) / 64, (B + spb - 1) / spb);
         if (W == 1)
-            hipLaunchKernelGGL(dwconv_small_bwd_kernel<1>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb);
+            hipLaunchKernelGGL(dwconv_small_bwd_kernel<1>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb, dres);
         else
-            hipLaunchKernelGGL(dwconv_small_bwd_kernel<3>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb);
+            hipLaunchKernelGGL(dwconv_small_bwd_kernel<3>, grid, dim3(256), 0, stream, dy, x, w, dx, dw, dbias, B, C, spb, dres);
         AC_CHECK_LAUNCH();
         return AC_OK;
     }
-    if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
-    if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+    if (W == 1) return launch_bwd<1>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
+    if (W <= 3) return launch_bwd<3>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
     if (H == W && (W == 15 || W == 7) && C % 4 == 0 && ac_aligned16(x) && ac_aligned16(dy))
-        return W == 15 ? launch_rows_bwd<15>(dy, x, w, dx, dw, dbias, B, C, stream)
-                       : launch_rows_bwd<7>(dy, x, w, dx, dw, dbias, B, C, stream);
-    if (H == 15 && W == 15) return launch_bwd<5, 15>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
-    if (H == 7 && W == 7) return launch_bwd<7, 7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
-    if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
-    return launch_bwd<5>(dy, x, w, dx, dw, dbias, B, H, W, C, stream);
+        return W == 15 ? launch_rows_bwd<15>(dy, x, w, dx, dw, dbias, B, C, stream, dres)
+                       : launch_rows_bwd<7>(dy, x, w, dx, dw, dbias, B, C, stream, dres);
+    if (H == 15 && W == 15) return launch_bwd<5, 15>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
+    if (H == 7 && W == 7) return launch_bwd<7, 7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
+    if (W == 7) return launch_bwd<7>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
+    return launch_bwd<5>(dy, x, w, dx, dw, dbias, B, H, W, C, stream, dres);
 }

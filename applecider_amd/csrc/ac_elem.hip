@@ -546,6 +546,26 @@ extern "C" int ac_add(const float *a, const float *b, float *y, int64_t n, float
     if (!a || !b || !y || n < 0) return AC_EINVAL;
     EW_LAUNCH(add_kernel, n, a, b, y, n, alpha);
 }
+// dst_j[i] += src[j * seg_len + i], j < nseg <= 4: the column sums a conv bank's backward pass forms in one buffer go
+// to the (separate) bias gradients of its convolutions in one launch
+struct AddSegs {
+    float *dst[4];
+};
+__global__ void add_segments_kernel(const float *__restrict__ src, AddSegs d, int seg_len, int n) {
+    GSTRIDE(i, n) {
+        const int j = (int)(i / seg_len);
+        d.dst[j][i - (int64_t)j * seg_len] += src[i];
+    }
+}
+extern "C" int ac_add_segments(const float *src, float *dst0, float *dst1, float *dst2, float *dst3, int32_t seg_len,
+                               int32_t nseg, ac_stream_t stream) {
+    if (!src || seg_len <= 0 || nseg < 1 || nseg > 4) return AC_EINVAL;
+    AddSegs d = {{dst0, dst1, dst2, dst3}};
+    for (int j = 0; j < nseg; ++j)
+        if (!d.dst[j]) return AC_EINVAL;
+    const int64_t n = (int64_t)seg_len * nseg;
+    EW_LAUNCH(add_segments_kernel, n, src, d, seg_len, (int)n);
+}
 extern "C" int ac_scale_by_dev(float *x, int64_t n, const float *s, ac_stream_t stream) {
     if (!x || !s || n < 0) return AC_EINVAL;
     EW_LAUNCH(scale_by_dev_kernel, n, x, n, s);

@@ -727,7 +727,7 @@ class _Linear(Function):
         ctx.has_b = b is not None
         aux = pre if save_pre else (y if act != ACT_NONE else None)
         ctx.save_for_backward(x16 if ctx.b16 else x2, w, aux, colscale)  # bf16 mode keeps the bf16 copy
-        ctx.wp, ctx.bp = w, b
+        ctx.wp, ctx.bp, ctx.csp = w, b, colscale
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -742,13 +742,17 @@ class _Linear(Function):
         if colscale is not None:
             # y = pre*gamma (+res): dpre = dy*gamma ; dgamma = sum_m dy*pre
             g = torch.empty_like(dy2)
-            dcs = torch.zeros_like(colscale)
+            cssink = _sink(ctx.csp)       # the layer scale's gradient accumulates straight into its sink
+            dcs = cssink if cssink is not None else torch.zeros_like(colscale)
             # the bias gradient of the Linear under the scale comes out of the same pass (into its sink)
             lsink = _sink(ctx.bp) if (not ctx.b16 and ctx.has_b and ctx.needs_input_grad[2]) else None
             _lib.check(_lib_().ac_layerscale_bwd(_p(dy2), _p(aux), _p(colscale), _p(g), None, _p(dcs),
                                                  _p(lsink), M, N, _stream()), "ac_layerscale_bwd")
             if lsink is not None:
                 _grad_written(ctx.bp)
+            if cssink is not None:
+                dcs = None
+                _grad_written(ctx.csp)
         bias_done = colscale is not None and lsink is not None
         db_tmp = None
         if colscale is None and (ctx.act != ACT_NONE or ctx.drop_p > 0.0):
@@ -1438,7 +1442,7 @@ class _DWConv7(Function):
     """x [B,H,W,C] NHWC, w [49,C], b [C]."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, with_shortcut=False):
         x, w = _chk(x, "x"), _chk(w, "w")
         B, H, W_, Cn = x.shape
         y = torch.empty_like(x)
@@ -1451,34 +1455,42 @@ class _DWConv7(Function):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         ctx.wp, ctx.bp = w, b
+        if with_shortcut:
+            # second output: the input itself, for the block's shortcut.  Both gradients then arrive in ONE backward
+            # call and the kernel adds the shortcut's while it stores d x (autograd's own sum of the two was an
+            # elementwise launch per block: 17 per step, 3 x the activation in traffic)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, w = ctx.saved_tensors
         dy = _chk(dy, "dy")
+        dres = _chk(dres, "dres") if dres is not None else None
         B, H, W_, Cn = x.shape
         dx = torch.empty_like(x)
         ws, bs = _sink(ctx.wp), _sink(ctx.bp)
         both = ws is not None and (bs is not None or not ctx.has_b)
         dw = ws if both else torch.zeros_like(w)
         db = bs if (both and ctx.has_b) else torch.zeros(Cn, device=x.device, dtype=torch.float32)
-        if _DWCONV_VARIANT:
-            _lib.check(_lib_().ac_dwconv7x7_bwd_v(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
-                                                  Cn, _DWCONV_VARIANT, _stream()), "ac_dwconv7x7_bwd_v")
-        else:
-            _lib.check(_lib_().ac_dwconv7x7_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_,
-                                                Cn, _stream()), "ac_dwconv7x7_bwd")
+        _lib.check(_lib_().ac_dwconv7x7_bwd_res(_p(dy), _p(x), _p(w), _p(dres), _p(dx), _p(dw), _p(db), B, H, W_,
+                                                Cn, _DWCONV_VARIANT, _stream()), "ac_dwconv7x7_bwd_res")
         if both:
             _grad_written(ctx.wp)
             if ctx.has_b:
                 _grad_written(ctx.bp)
-            return dx, None, None
-        return dx, dw, (db if ctx.has_b else None)
+            return dx, None, None, None
+        return dx, dw, (db if ctx.has_b else None), None
 
 
 def dwconv7x7(x, w, b):
     return _DWConv7.apply(x, w, b)
+
+
+def dwconv7x7_shortcut(x, w, b):
+    """(dwconv(x), x): the second output feeds the ConvNeXt block's shortcut, so that the block input's two gradient
+    contributions meet inside the depthwise backward kernel (ac_dwconv7x7_bwd_res)."""
+    return _DWConv7.apply(x, w, b, True)
 
 
 class _PatchConv2x2(Function):
@@ -2054,6 +2066,7 @@ class _ConvGroup1d(Function):
             ctx.xplanes = xplanes
         ctx.fused_ln = ln_gamma is not None
         ctx.params = (list(wb[0::2]), ln_gamma, ln_beta)
+        ctx.bparams = list(wb[1::2])
         ctx.tail = False
         if pw_w is not None:
             # LayerNorm + GELU + 1x1 conv + MaxPool(4) behind the conv bank in one kernel (ac_tail.hip): nothing of row
@@ -2217,8 +2230,21 @@ class _ConvGroup1d(Function):
         else:
             xpad, *ws = ctx.saved_tensors
 
+        # the conv biases' gradients = slices of the column sums the LayerNorm / tail backward kernel formed: one
+        # launch adds them into the biases' gradient sinks (they were nconv AccumulateGrad launches per bank)
+        bias_direct = False
+        if bias_sums is not None and nconv <= 4 and all(ctx.has_b):
+            bsinks = [_sink(bp) for bp in ctx.bparams]
+            if all(t is not None for t in bsinks):
+                ptrs = [_p(t) for t in bsinks] + [None] * (4 - nconv)
+                _lib.check(_lib_().ac_add_segments(_p(bias_sums), ptrs[0], ptrs[1], ptrs[2], ptrs[3], Cout, nconv,
+                                                   _stream()), "ac_add_segments")
+                for bp in ctx.bparams:
+                    _grad_written(bp)
+                bias_direct = True
+
         def bias_grad(j):
-            if not ctx.has_b[j]:
+            if not ctx.has_b[j] or bias_direct:
                 return None
             if bias_sums is not None:
                 return bias_sums[j * Cout:(j + 1) * Cout]
@@ -2432,6 +2458,7 @@ class _Embed(Function):
                                         _p(h), B, L, D, _stream()), "ac_embed_fwd")
         ctx.save_for_backward(x8, tw, tb)
         ctx.dims = (B, L, D)
+        ctx.params, ctx.cls_shape = (W8, bias, tw, tb, cls), cls.shape
         return h
 
     @staticmethod
@@ -2440,11 +2467,22 @@ class _Embed(Function):
         B, L, D = ctx.dims
         dh = _chk(dh, "dh")
         dev = dh.device
-        dW = torch.zeros(D, 8, device=dev, dtype=torch.float32)
-        db, dtw, dtb, dcls = (torch.zeros(D, device=dev, dtype=torch.float32) for _ in range(4))
+        # the kernel accumulates with atomics: parameters that own a slice of the flat gradient buffer take their sums
+        # directly (no zeroed temporaries, no AccumulateGrad launches)
+        sinks = [_sink(p) for p in ctx.params]
+        direct = all(s is not None for s in sinks)
+        if direct:
+            dW, db, dtw, dtb, dcls = sinks
+        else:
+            dW = torch.zeros(D, 8, device=dev, dtype=torch.float32)
+            db, dtw, dtb, dcls = (torch.zeros(D, device=dev, dtype=torch.float32) for _ in range(4))
         _lib.check(_lib_().ac_embed_bwd(_p(dh), _p(x8), _p(tw), _p(tb), _p(dW), _p(db), _p(dtw),
                                         _p(dtb), _p(dcls), B, L, D, _stream()), "ac_embed_bwd")
-        return None, dW, db, dtw, dtb, dcls
+        if direct:
+            for p in ctx.params:
+                _grad_written(p)
+            return None, None, None, None, None, None
+        return None, dW, db, dtw, dtb, dcls.reshape(ctx.cls_shape)
 
 
 def embed(x8, W8, bias, tw, tb, cls):

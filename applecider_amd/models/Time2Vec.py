@@ -111,7 +111,7 @@ class Encoder(nn.Module):
 def embed_tokens(in_proj: InProj8, time2vec: Time2Vec, cls_tok, data):
     """CLS + in_proj(x) + time2vec(x[...,0]) in one kernel; data is (B, L, 7)."""
     x8 = H.pad_channels(data, 8)
-    return H.embed(x8, in_proj.weight, in_proj.bias, time2vec.tw, time2vec.tb, cls_tok.reshape(-1))
+    return H.embed(x8, in_proj.weight, in_proj.bias, time2vec.tw, time2vec.tb, cls_tok)   # (the parameters themselves: gradient sinks)
 
 
 def extend_pad_mask(pad):

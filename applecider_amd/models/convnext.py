@@ -48,10 +48,11 @@ class ConvNeXtBlock(nn.Module):
         self.mlp = Mlp(dim)
 
     def forward(self, x):  # x: [B, H, W, C]
-        h = self.conv_dw(x)
+        # (depthwise output, the input again for the shortcut: their gradients meet in the depthwise backward kernel)
+        h, shortcut = H.dwconv7x7_shortcut(x, self.conv_dw.weight, self.conv_dw.bias)
         h = self.norm(h)
         m = self.mlp
-        return H.mlp(h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu", residual=x,
+        return H.mlp(h, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, "gelu", residual=shortcut,
                      colscale=self.gamma)
 
 

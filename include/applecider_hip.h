@@ -331,6 +331,12 @@ int ac_dwconv7x7_fwd_v(const float *x, const float *w, const float *bias, float 
                        int32_t W, int32_t C, int32_t variant, ac_stream_t stream);
 int ac_dwconv7x7_bwd_v(const float *dy, const float *x, const float *w, float *dx, float *dw, float *dbias,
                        int32_t B, int32_t H, int32_t W, int32_t C, int32_t variant, ac_stream_t stream);
+/* ... and with the ConvNeXt block's shortcut folded in (timm block at astrominn.py:12-17: out = x + gamma * mlp(..dw(x))):
+ * dx = depthwise backward(dy) + dres, dres [B, H, W, C] nullable - the block input's two gradient contributions meet
+ * where dx is stored instead of in a separate elementwise pass. */
+int ac_dwconv7x7_bwd_res(const float *dy, const float *x, const float *w, const float *dres, float *dx, float *dw,
+                         float *dbias, int32_t B, int32_t H, int32_t W, int32_t C, int32_t variant,
+                         ac_stream_t stream);
 /* mean over the HW positions: [B, HW, C] -> [B, C]; bwd broadcasts dy/HW. */
 int ac_avgpool_fwd(const float *x, float *y, int32_t B, int32_t HW, int32_t C, ac_stream_t stream);
 int ac_avgpool_bwd(const float *dy, float *dx, int32_t B, int32_t HW, int32_t C,
@@ -499,6 +505,10 @@ int ac_l2norm_bwd(const float *dy, const float *y, const float *norm, float *dx,
                   int32_t C, ac_stream_t stream);
 /* softmax over the last dim (use_probabilities, astrominn.py:297). */
 int ac_softmax_fwd(const float *x, float *y, int64_t rows, int32_t C, ac_stream_t stream);
+/* dst_j[i] += src[j * seg_len + i] for j < nseg <= 4 (unused dst pointers may be NULL): one launch hands the
+ * concatenated column sums of a conv bank's backward pass to the bias gradients of its convolutions. */
+int ac_add_segments(const float *src, float *dst0, float *dst1, float *dst2, float *dst3, int32_t seg_len,
+                    int32_t nseg, ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Losses: one kernel computes the mean loss AND dlogits (= dloss/dlogits for mean).

@@ -1040,3 +1040,34 @@ def test_gelu_through_rational_erf_outside_exact_mode(dev, mode):
         close(bld.grad, bl64.grad, tol=2 * ptol, name="linear+gelu db")
     finally:
         H.set_math("f32")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,H_,C", [(513, 15, 96), (343, 7, 192), (64, 3, 384), (33, 1, 768), (5, 15, 96), (4, 7, 40), (3, 9, 32)])
+def test_dwconv_with_the_block_shortcut(dev, B, H_, C, variant):
+    """ConvNeXt block (timm block at astrominn.py:12-17): out = x + f(dw(x)).  dwconv7x7_shortcut returns (dw(x), x) and
+    its backward kernel adds the shortcut's gradient where it stores dx (ac_dwconv7x7_bwd_res; every kernel family:
+    pipelined 15x15 / 7x7, small 3x3 / 1x1, whole-row, generic) - equal to torch's autograd sum of the two paths."""
+    from applecider_amd import hipops as H
+    x = g(dev, B, C, H_, H_, seed=1).requires_grad_()
+    w = (g(dev, C, 1, 7, 7, seed=2) / 7).requires_grad_()
+    b = g(dev, C, seed=3).requires_grad_()
+    y = F.conv2d(x, w, b, padding=3, groups=C)
+    out = x * 0.5 + torch.tanh(y)                      # a shortcut with its own scale and a nonlinear branch
+    go = g(dev, *y.shape, seed=4)
+    out.backward(go)
+    H._DWCONV_VARIANT = variant
+    try:
+        xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_()
+        wd = w.detach().reshape(C, 49).t().contiguous().to(dev).requires_grad_()
+        bd = b.detach().to(dev).requires_grad_()
+        yd, sc = H.dwconv7x7_shortcut(xd, wd, bd)
+        od = sc * 0.5 + torch.tanh(yd)
+        od.backward(go.permute(0, 2, 3, 1).contiguous().to(dev))
+        torch.cuda.synchronize()
+    finally:
+        H._DWCONV_VARIANT = 0
+    close(od.permute(0, 3, 1, 2), out, name="out")
+    close(xd.grad.permute(0, 3, 1, 2), x.grad, name="dx (both paths)")
+    close(wd.grad.t().reshape(C, 1, 7, 7), w.grad, name="dw")
+    close(bd.grad, b.grad, name="db")
