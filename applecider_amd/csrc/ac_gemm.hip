@@ -36,6 +36,12 @@ struct GemmParams {
     int epi_var;  // compile-time epilogue variant (AC_EPI_VARIANTS index) or EPI_GENERIC
     // ac_gemm_batched: gridDim.x = batch * tiles; product z reads / writes its operands bs_* elements further on
     int64_t bs_a, bs_b, bs_c;
+    // ac_gemm_grouped: product z takes its three base pointers from here instead (ngrp > 0): independent products of one
+    // shape whose operands are separate allocations (the weight gradients of a ConvNeXt stage's blocks, of the encoder
+    // layers).  By value in the kernel arguments: nothing to upload, and a captured hipGraph replays them.
+    static constexpr int MAX_GROUPS = 16;
+    const void *grp[3 * MAX_GROUPS];
+    int ngrp;
 };
 
 // Workgroup -> (output tile, K piece).  One K piece: XCD-aware tile order (workgroups that share an XCD, bid % 8, walk
@@ -64,6 +70,12 @@ __device__ __forceinline__ void batch_select(const GemmParams &p, int &wg, ac_ge
     const int per = p.tiles_m * p.tiles_n, z = wg / per;
     wg -= z * per;
     d = p.d;
+    if (p.ngrp > 0) {
+        d.a.ptr = p.grp[3 * z];
+        d.b.ptr = p.grp[3 * z + 1];
+        d.c.ptr = const_cast<void *>(p.grp[3 * z + 2]);
+        return;
+    }
     d.a.ptr = (const float *)d.a.ptr + (int64_t)z * p.bs_a;
     d.b.ptr = (const float *)d.b.ptr + (int64_t)z * p.bs_b;
     d.c.ptr = (float *)d.c.ptr + (int64_t)z * p.bs_c;
@@ -1401,9 +1413,15 @@ int vec_epilogue_ok(const ac_gemm_desc &d, int accumulate) {
 
 }  // namespace
 
-static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int64_t bs_a, int64_t bs_b, int64_t bs_c) {
+static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int64_t bs_a, int64_t bs_b, int64_t bs_c,
+                    const void *const *grp = nullptr) {
     if (!dp) return AC_EINVAL;
     ac_gemm_desc d = *dp;
+    if (grp) {   // grouped: the descriptor's pointers are those of product 0
+        d.a.ptr = grp[0];
+        d.b.ptr = grp[1];
+        d.c.ptr = const_cast<void *>(grp[2]);
+    }
     hipStream_t stream = (hipStream_t)stream_;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return AC_EINVAL;
     if (d.mode < 0 || d.mode > 2) return AC_EINVAL;
@@ -1463,6 +1481,15 @@ static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int6
     GemmParams p;
     p.d = d;
     p.bs_a = bs_a; p.bs_b = bs_b; p.bs_c = bs_c;
+    p.ngrp = 0;
+    if (grp) {
+        if (batch < 1 || batch > GemmParams::MAX_GROUPS || !use_mfma) return AC_EINVAL;
+        p.ngrp = batch;
+        for (int i = 0; i < 3 * batch; ++i) {
+            if (!grp[i] || !ac_aligned16(grp[i])) return AC_EALIGN;
+            p.grp[i] = grp[i];
+        }
+    }
     if (!use_mfma) {
         if (d.accumulate == 3 || batch > 1) return AC_EINVAL;   // split-K slabs / batches exist on the matrix-core kernels only
         // split_k is only a scheduling hint: the scalar kernel computes whole dot products
@@ -1501,10 +1528,15 @@ static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int6
     dim3 grid(p.tiles_m * p.tiles_n, d.split_k);
     const size_t lds_f32 = 4 * TILE_FLOATS * sizeof(float);  // 64 KB
     const size_t lds_bf16 = 4 * TILE_FLOATS * sizeof(short); // 32 KB
-    if (batch > 1) {
+    if (batch > 1 || p.ngrp > 0) {
         // the per-frequency products of the frequency-domain convolutions (ac_fft.hip): plain fp32 matrices, no
-        // epilogue beyond store / +=, exact fp32 or split-bf16 arithmetic
-        if (d.split_k != 1 || d.math == AC_MATH_BF16 || (int64_t)batch * grid.x > 0x7FFFFFFF) return AC_EINVAL;
+        // epilogue beyond store / +=, exact fp32 or split-bf16 arithmetic.  Grouped products (ac_gemm_grouped) may also
+        // be cut over K: their pieces meet in C with atomics (weight gradients into the gradient sinks).
+        if ((d.split_k != 1 && !(p.ngrp > 0 && p.d.accumulate == 2)) || d.math == AC_MATH_BF16 ||
+            (int64_t)batch * grid.x > 0x7FFFFFFF)
+            return AC_EINVAL;
+        if (d.bias || d.pre_out || d.act || d.dact || d.residual || d.colscale || d.mask16 || d.c16 || d.drop_p > 0.f)
+            return AC_EINVAL;
         if ((bs_a % 4) || (bs_b % 4) || (bs_c % 4)) return AC_EALIGN;
         grid.x *= batch;
         if (d.math == AC_MATH_BF16X3) {
@@ -1551,6 +1583,11 @@ extern "C" int ac_gemm_batched(const ac_gemm_desc *dp, int32_t batch, int64_t bs
                                ac_stream_t stream) {
     if (batch < 1) return AC_EINVAL;
     return gemm_run(dp, stream, batch, bs_a, bs_b, bs_c);
+}
+
+extern "C" int ac_gemm_grouped(const ac_gemm_desc *dp, int32_t groups, const void *const *ptrs, ac_stream_t stream) {
+    if (groups < 1 || groups > GemmParams::MAX_GROUPS || !ptrs) return AC_EINVAL;
+    return gemm_run(dp, stream, groups, 0, 0, 0, ptrs);
 }
 
 extern "C" int ac_cast_bf16(const float *x, void *y, int64_t n, ac_stream_t stream) {

@@ -343,6 +343,16 @@ __global__ __launch_bounds__(512, 2) void tail_bwd_dx_kernel(TailParams p) {
     for (int j = 0; j < NV; ++j) adg[j] = adb[j] = adx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float invK = 1.0f / (float)K;
     static_assert((R / 4) * (N / 4) <= NT, "one d out work item per thread");
+    constexpr bool WRES = K / 32 <= NW && KS <= 4;       // (192, 64): 32 registers of w^T per wave
+    bf16x8 wrh[WRES ? KS : 1], wrl[WRES ? KS : 1];
+    if constexpr (WRES) {
+        const int64_t boff = (int64_t)((w < K / 32 ? w : 0) * 32 + (lane & 31)) * N + 8 * lh;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            wrh[s2] = ac_gload<bf16x8>((const short *)p.w_hi + boff + 16 * s2);
+            wrl[s2] = ac_gload<bf16x8>((const short *)p.w_lo + boff + 16 * s2);
+        }
+    }
     RowRegs<K, TPR> x;
     DoutRegs<N, DP> dreg;
     float mu_n = 0.f, rs_n = 0.f;
@@ -366,19 +376,33 @@ __global__ __launch_bounds__(512, 2) void tail_bwd_dx_kernel(TailParams p) {
             rs_n = p.rstd[nrow0 + r];
         }
         __syncthreads();
-        for (int tile = w; tile < K / 32; tile += NW) {
-            // d z tile: reduction over the N output channels; B = planes of w^T [K][N] straight from L2
-            f32x16 acc = zero16();
-            const int64_t boff = (int64_t)(tile * 32 + (lane & 31)) * N + 8 * lh;
+        if constexpr (WRES) {
+            // one tile per wave (K / 32 <= NW): its fragments of w^T never leave the registers
+            if (w < K / 32) {
+                f32x16 acc = zero16();
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 bh = ac_gload<bf16x8>((const short *)p.w_hi + boff + 16 * s);
-                const bf16x8 bl = ac_gload<bf16x8>((const short *)p.w_lo + boff + 16 * s);
-                const bf16x8 ah = frag_kc<DP>(dhi, 0, s, lane), al = frag_kc<DP>(dlo, 0, s, lane);
-                acc = mma3(ah, al, bh, bl, acc);
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 ah = frag_kc<DP>(dhi, 0, s, lane), al = frag_kc<DP>(dlo, 0, s, lane);
+                    acc = mma3(ah, al, wrh[s], wrl[s], acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dz[(8 * (e >> 2) + 4 * lh + (e & 3)) * ZF + w * 32 + (lane & 31)] = acc[e];
             }
+        } else {
+            for (int tile = w; tile < K / 32; tile += NW) {
+                // d z tile: reduction over the N output channels; B = planes of w^T [K][N] straight from L2
+                f32x16 acc = zero16();
+                const int64_t boff = (int64_t)(tile * 32 + (lane & 31)) * N + 8 * lh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dz[(8 * (e >> 2) + 4 * lh + (e & 3)) * ZF + tile * 32 + (lane & 31)] = acc[e];
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 bh = ac_gload<bf16x8>((const short *)p.w_hi + boff + 16 * s);
+                    const bf16x8 bl = ac_gload<bf16x8>((const short *)p.w_lo + boff + 16 * s);
+                    const bf16x8 ah = frag_kc<DP>(dhi, 0, s, lane), al = frag_kc<DP>(dlo, 0, s, lane);
+                    acc = mma3(ah, al, bh, bl, acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dz[(8 * (e >> 2) + 4 * lh + (e & 3)) * ZF + tile * 32 + (lane & 31)] = acc[e];
+            }
         }
         __syncthreads();
         // ---- LayerNorm backward of this thread's elements (ac_rows.hip layernorm_bwd_sub_kernel, with d y = d z)

@@ -134,7 +134,9 @@ def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) 
 def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
          ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
          accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0, c16=None, ld_c16=0,
-         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0):
+         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0, group=None):
+    """group = [(a_ptr, b_ptr, c_ptr), ...] (device addresses): that many independent products of this shape in ONE
+    launch (ac_gemm_grouped; a / b / c then only carry strides)."""
     d = GemmDesc()
     d.mode, d.math = mode, (_MATH if math is None else math)
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -150,6 +152,11 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     d.mask16, d.ld_mask16 = _p(mask16), ld_mask16
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.drop_step = _p(_STEP_DEV) if drop_p > 0.0 else None
+    if group is not None:
+        flat = [ptr for trip in group for ptr in trip]
+        arr = (C.c_void_p * len(flat))(*flat)
+        _lib.check(_lib_().ac_gemm_grouped(C.byref(d), len(group), arr, _stream()), "ac_gemm_grouped")
+        return
     _lib.check(_lib_().ac_gemm(C.byref(d), _stream()), "ac_gemm")
 
 
@@ -666,6 +673,79 @@ def _exact_split(nkt: int, split: int) -> int:
     return -(-nkt // per)
 
 
+# --------------------------------------------------------------------------- grouped weight gradients
+# The weight gradients of nn.Linear layers that share a shape are independent small products: 9 ConvNeXt blocks of a
+# stage x (fc1, fc2), 4 encoder layers x (qkv, out, linear1, linear2) ... 68 launches per step at ~55 us each, a few
+# dozen workgroups with a split-K epilogue of atomics, 1.5 TB/s of their algorithmic bytes (round 3's dominant family).
+# They are collected while backward runs and launched as ONE grouped product per shape (ac_gemm_grouped: the chip fills
+# with 2-3 workgroups per CU, ramp-up and drain are paid once): when _WGRAD_GROUP_SIZE are waiting, when the same stream
+# moves on to another row count (= another stage), and at the end of the backward pass (autograd engine callback).
+# Only products that accumulate into a gradient sink are deferred.
+_WGRAD_GROUPS = True      # tests / A-B: False = every weight gradient launched where it is formed
+_WGRAD_GROUP_SIZE = 3     # launch as soon as this many products of a shape wait: three fill the chip, and nothing but a
+                          # remainder of <= 2 per shape is left for the end of the backward pass
+_wg_queue: dict = {}
+_wg_armed = False
+_wg_pending: set = set()  # ids of parameters whose gradient product is still waiting
+
+
+def grad_is_deferred(param) -> bool:
+    """True while `param`'s weight-gradient product sits in the grouped-launch queue: autograd's post-accumulate hook of
+    that parameter fires when its backward node returns (with no gradient), which is NOT yet the moment its slice of
+    the flat gradient buffer is complete (ddp.GradBuckets skips that report; _grad_written follows at the launch)."""
+    return id(param) in _wg_pending
+
+
+def _wg_flush_key(key):
+    """Launch the waiting products of one shape on the CURRENT stream (during backward that is the stream of the node
+    that triggered the flush = the stream that produced the operands; at the end of backward the caller's stream, after
+    it waited for the producers)."""
+    items = _wg_queue.pop(key, None)
+    if not items:
+        return
+    Nw, Kw, rows, split, _sid = key
+    g, x2, dw = items[0][:3]
+    if len(items) == 1:
+        gemm(AC_GEMM_TN, Nw, Kw, rows, mat(_p(g), Nw), mat(_p(x2), Kw), mat(_p(dw), Kw), accumulate=2, split_k=split)
+    else:
+        gemm(AC_GEMM_TN, Nw, Kw, rows, mat(_p(g), Nw), mat(_p(x2), Kw), mat(_p(dw), Kw), accumulate=2, split_k=split,
+             group=[(_p(i[0]), _p(i[1]), _p(i[2])) for i in items])
+    for i in items:
+        _wg_pending.discard(id(i[3]))
+        _grad_written(i[3])
+
+
+def flush_weight_gradients():
+    """Launch every weight-gradient product still waiting (end of backward; also callable directly)."""
+    global _wg_armed
+    _wg_armed = False
+    if not _wg_queue:
+        return
+    cur = torch.cuda.current_stream()
+    for st in {i[4].cuda_stream: i[4] for q in _wg_queue.values() for i in q}.values():
+        if st != cur:
+            cur.wait_stream(st)       # operands produced on a branch stream
+    for key in list(_wg_queue.keys()):
+        _wg_flush_key(key)
+
+
+def _defer_weight_grad(Nw, Kw, rows, g, x2, dw, wp):
+    global _wg_armed
+    st = torch.cuda.current_stream()
+    sid = st.cuda_stream
+    for key in [k for k in _wg_queue if k[4] == sid and k[2] != rows]:
+        _wg_flush_key(key)
+    key = (Nw, Kw, rows, _split_for(Nw, Kw, rows), sid)
+    q = _wg_queue.setdefault(key, [])
+    q.append((g, x2, dw, wp, st))
+    _wg_pending.add(id(wp))
+    if len(q) >= _WGRAD_GROUP_SIZE:
+        _wg_flush_key(key)
+    if not _wg_armed:
+        _wg_armed = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_weight_gradients)
+
+
 # --------------------------------------------------------------------------- Linear
 class _Linear(Function):
     """y = [drop](act(x @ w.T + b) [* colscale]) [+ residual]   (nn.Linear + fused epilogue).
@@ -819,6 +899,10 @@ class _Linear(Function):
             if ctx.b16:  # x2 is the bf16 copy saved by forward
                 gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M), math=_lib.MATH_BF16_IN)
+            elif (wsink is not None and _WGRAD_GROUPS and _big(N, K, M) and N % 4 == 0 and K % 4 == 0
+                  and g.is_contiguous() and x2.is_contiguous()):
+                _defer_weight_grad(N, K, M, g, x2, wsink, ctx.wp)      # one grouped launch per shape, later
+                wsink = dw = None
             else:
                 gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M))

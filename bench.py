@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0}
 MFMA_ISSUE_FACTOR = {"bf16": 1, "f32": 1, "bf16x3": 3}
 HBM_PEAK_GBS = 8000.0
+GUIDE_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: float4 copy, measured (79 % of the 8 TB/s spec)
 FUSION_CFG = {"mode": "all", "p_d_model": 128, "p_n_heads": 8, "p_n_layers": 4, "p_dropout": 0.4,
               "max_len": 257, "num_classes": 5, "hidden_dim": 64, "fusion": "avg", "lr": 1e-3,
               "beta1": 0.9, "beta2": 0.999, "weight_decay": 0.01}  # brew_cider.py:195-215
@@ -85,7 +86,8 @@ class KernelTimer:
                 cb = (4 * mn if c.ptr else 0) + (4 * mn if kw.get("accumulate") == 1 else 0)
                 cb += 2 * mn * (kw.get("c16") is not None) + 2 * mn * (kw.get("mask16") is not None)
                 cb += 4 * mn * sum(kw.get(k) is not None for k in ("pre_out", "aux", "residual"))
-                self.records.setdefault(names[mode], []).append((s, e, 2.0 * M * N * K, es * ab + cb))
+                ng = len(kw["group"]) if kw.get("group") else 1      # grouped launch: that many products of this shape
+                self.records.setdefault(names[mode], []).append((s, e, ng * 2.0 * M * N * K, ng * (es * ab + cb)))
         H.gemm = timed
 
     def wrap_conv_window(self, H):
@@ -241,6 +243,21 @@ class KernelTimer:
         return out
 
 
+def csrc_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: applecider_amd/csrc/*.hip, *.h and the C-ABI header, in
+    name order.  Recorded with every committed counter file and compared here (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "applecider_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "applecider_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "applecider_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measure_ceilings(H, dev):
     """on-box ceilings beside the vendor peaks.  HIP events on the launch stream.
       copy   16-byte-per-lane streaming copy of a 1 GiB buffer (read + write bytes / time)
@@ -263,7 +280,12 @@ def measure_ceilings(H, dev):
     e0.record()
     torch.cuda.synchronize()
     out["copy_GBps"] = round(2.0 * n * reps / (s0.elapsed_time(e0) * 1e-3) / 1e9, 1)
-    out["copy_note"] = "1 GiB -> 1 GiB, 16 B per lane, 2048 workgroups grid-stride; bytes = read + write"
+    out["copy_note"] = ("1 GiB -> 1 GiB, 16 B per lane, eight loads in flight per lane, non-temporal, 2048 workgroups "
+                        "grid-stride; bytes = read + write")
+    # MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy: fractions "of the measured ceiling" are taken against
+    # the larger of the two, so that a slow probe cannot flatter a kernel
+    out["hbm_ceiling_GBps"] = max(out["copy_GBps"], GUIDE_COPY_GBS)
+    out["hbm_ceiling_note"] = "max(this box's copy probe, the guide's 6290 GB/s float4 copy)"
     del src, dst
     ops = (torch.rand(64 * 8 * 64 * 64, device=dev) * 2 - 1).to(H._H16)
     wgs = 256
@@ -775,10 +797,18 @@ def main():
     # (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # this same command, FETCH_SIZE doubled for gfx950); None when the kernel is not in that file.
     try:
-        pmc_file = "r03_pmc_hbm_traffic_%s.json" % args.math
-        if not os.path.exists(os.path.join(ROOT, "profiles", pmc_file)):
-            pmc_file = "r02_pmc_hbm_traffic_%s.json" % args.math
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic_%s.json" % args.math)))
+        pmc_file = os.path.basename(cands[-1])          # the latest round's passes
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        # the counters describe the kernels they were taken on: a file whose recorded digest of the kernel sources
+        # (tools/pmc_merge.py) is not the digest of the sources in this tree is refused, not quoted
+        if pmc.get("_csrc_sha16") != csrc_digest():
+            roofline["traffic"] = None
+            roofline["traffic_source"] = ("profiles/" + pmc_file + " REFUSED: taken on kernel sources " +
+                                          str(pmc.get("_csrc_sha16", "unrecorded")) + ", this tree has " + csrc_digest() +
+                                          " (re-run tools/gpu_evidence.sh and commit its pmc_hbm_traffic file)")
+            raise LookupError("stale traffic file")
         want = {"gemm<TN>": "gemm_bf16in_kernelILb1ELi2ELi2EE", "gemm<NT>": "gemm_bf16in_kernelILb0ELi2ELi2EE",
                 "conv1d_window": "conv1d_window", "conv1d_wgrad": "conv1d_wgrad_kernel"}.get(dom_name)
         if args.math == "bf16x3" and dom_name.startswith("gemm"):
@@ -858,7 +888,7 @@ def main():
         out["ceilings"] = ceilings
         if "copy_GBps" in ceilings:
             roofline["frac_of_measured_ceiling"] = round(
-                roofline["achieved"] / (ceilings["copy_GBps"] if roofline["bound"] == "hbm" else
+                roofline["achieved"] / (ceilings["hbm_ceiling_GBps"] if roofline["bound"] == "hbm" else
                                          ceilings.get("mfma_bf16_16x16x32_2wave_per_simd_TFLOPs", peak)), 4)
     if other is not None:
         out["roofline_other_class"] = other
@@ -901,9 +931,9 @@ def main():
                                    "measured": "HIP-event bracket around each launch (x, dy read once, dx written once)"}
         out["roofline_hbm_bwd"].update(pending_rocprof.get("roofline_hbm_bwd", {}))
         if ceilings and "copy_GBps" in ceilings:
-            out["roofline_hbm_bwd"]["frac_of_measured_ceiling"] = round(gbs / ceilings["copy_GBps"], 4)
+            out["roofline_hbm_bwd"]["frac_of_measured_ceiling"] = round(gbs / ceilings["hbm_ceiling_GBps"], 4)
     if "roofline_hbm" in out and ceilings and "copy_GBps" in ceilings:
-        out["roofline_hbm"]["frac_of_measured_ceiling"] = round(out["roofline_hbm"]["achieved"] / ceilings["copy_GBps"], 4)
+        out["roofline_hbm"]["frac_of_measured_ceiling"] = round(out["roofline_hbm"]["achieved"] / ceilings["hbm_ceiling_GBps"], 4)
     if world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_full_model
         from oracle.weights import closed_form_state_dict

@@ -649,6 +649,11 @@ typedef struct ac_fft_rows_desc {
                             nothing; 1 (diagnostic): the exact request, workgroups of other kernels may share the CU */
 } ac_fft_rows_desc;
 int ac_gemm_batched(const ac_gemm_desc *d, int32_t batch, int64_t bs_a, int64_t bs_b, int64_t bs_c, ac_stream_t stream);
+/* `groups` (<= 16) independent products of ONE shape / mode / math in one launch: product g uses the descriptor with
+ * a.ptr, b.ptr, c.ptr replaced by ptrs[3 g], ptrs[3 g + 1], ptrs[3 g + 2] (HOST array of device pointers, 16-byte
+ * aligned; read during the call).  No epilogue beyond store / += ; split_k > 1 with accumulate = 2 (atomics) is allowed:
+ * the weight gradients of a stage's ConvNeXt blocks / of the encoder layers in one launch that fills the chip. */
+int ac_gemm_grouped(const ac_gemm_desc *d, int32_t groups, const void *const *ptrs, ac_stream_t stream);
 int ac_fft_rows_fwd(const ac_fft_rows_desc *d, ac_stream_t stream);
 int ac_fft_rows_inv(const ac_fft_rows_desc *d, ac_stream_t stream);
 int ac_fft_taps_fwd(const float *w, int32_t Cout, int32_t Cin, int32_t k, int32_t logn, int32_t radix3, const float *tw,

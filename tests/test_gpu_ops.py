@@ -1071,3 +1071,46 @@ def test_dwconv_with_the_block_shortcut(dev, B, H_, C, variant):
     close(xd.grad.permute(0, 3, 1, 2), x.grad, name="dx (both paths)")
     close(wd.grad.t().reshape(C, 1, 7, 7), w.grad, name="dw")
     close(bd.grad, b.grad, name="db")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_grouped_weight_gradients_equal_separate_launches(dev, mode):
+    """Round 4: weight gradients of same-shaped nn.Linear layers are collected during backward and launched as one
+    grouped product per shape (ac_gemm_grouped) - at a stage change, at 16 waiting, at the end of backward.  Same sums
+    as one launch per layer (split-K atomics: equal to rounding), the sinks are complete when backward() returns, and
+    nothing is left in the queue."""
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    try:
+        torch.manual_seed(3)
+        M1, M2 = 4608, 1152
+        shapes = [(384, 96), (96, 384)] * 5                  # alternating like fc1 / fc2 of a ConvNeXt stage
+        x0 = torch.randn(M1, 96, device=dev)
+        ws0 = [torch.randn(n, k, device=dev) / math.sqrt(k) for n, k in shapes]
+        tail0 = [torch.randn(64, 96, device=dev) / 10 for _ in range(18)]   # 18 layers of one shape at another row count
+        res = {}
+        for grouped in (True, False):
+            H._WGRAD_GROUPS = grouped
+            try:
+                ws = [torch.nn.Parameter(w.clone()) for w in ws0 + tail0]
+                for w in ws:
+                    w.grad = torch.zeros_like(w)
+                x = x0.clone().requires_grad_()
+                h = x
+                for i in range(0, 10, 2):
+                    h = H.linear(H.linear(h, ws[i], None, act="gelu"), ws[i + 1], None, residual=h)
+                h2 = h[:M2].contiguous()
+                out = 0
+                for w in ws[10:]:
+                    out = out + H.linear(h2, w, None).sum()
+                (h.square().sum() + out).backward()
+                assert not H._wg_queue and not H._wg_pending, "weight gradients still waiting after backward()"
+                torch.cuda.synchronize()
+            finally:
+                H._WGRAD_GROUPS = True
+            res[grouped] = [w.grad.clone() for w in ws] + [x.grad.clone()]
+        for i, (a, b) in enumerate(zip(res[True], res[False])):
+            assert float(b.abs().max()) > 0
+            close(a, b, tol=2e-6, name=f"grad {i}")
+    finally:
+        H.set_math("f32")

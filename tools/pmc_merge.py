@@ -14,4 +14,19 @@ for k in sorted(set(fetch) | set(write)):
     fb, wb = 2.0 * f["sum"] * 1024.0, w["sum"] * 1024.0
     out[k] = {"launches": n, "fetch_GB": round(fb / 1e9, 3), "write_GB": round(wb / 1e9, 3),
               "per_launch_MB": round((fb + wb) / n / 1e6, 2)}
+# provenance: digest of the kernel sources these counters were taken on (bench.py refuses a file whose digest is not
+# that of the sources it runs with), steps covered, per-step total
+import glob, hashlib, os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "applecider_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "applecider_amd", "csrc", "*.h")) +
+                [os.path.join(root, "include", "applecider_hip.h")]):
+    h.update(os.path.basename(f).encode())
+    h.update(open(f, "rb").read())
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+out["_csrc_sha16"] = h.hexdigest()[:16]
+out["_how"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 "
+               "--warmup 1 --math bf16x3 --no-graph --no-branch-streams --no-h2d --no-ceilings --no-fast-mode "
+               "--no-cpu-baseline`; FETCH_SIZE doubled for gfx950; %d steps incl. the roofline pass" % steps)
+out["_total_GB_per_step"] = round(sum(v["fetch_GB"] + v["write_GB"] for v in out.values() if isinstance(v, dict)) / steps, 1)
 json.dump(out, sys.stdout, indent=1)
