@@ -177,6 +177,7 @@ SIGNATURES = {
     "ac_ceil_mfma": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "ac_gemm_batched": [C.POINTER(GemmDesc), _I32, _I64, _I64, _I64, _P],
     "ac_gemm_grouped": [C.POINTER(GemmDesc), _I32, C.POINTER(C.c_void_p), _P],
+    "ac_collate_photometry": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ac_add_segments": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "ac_spectail_supported": [_I64, _I32, _I32],
     "ac_spectail_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],

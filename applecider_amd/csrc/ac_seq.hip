@@ -535,3 +535,47 @@ extern "C" int ac_mpt_loss_fwd_bwd(const float *f_hat, const float *b_hat, const
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Photometry collate on the device (src/applecider/datasets/photo_dataset.py:117-152, the legacy 5-modal
+// collate src/applecider/models/Time2Vec.py:18-45, HyraxBaselineCLS.to_tensor :152-166): the host ships the RAGGED light
+// curves back to back (flat [sum of lengths, 7] + per-sample row offset and length) - no padded host copy, no host
+// arithmetic - and one kernel pads / truncates every sample to L rows, standardises the first four channels
+//     out[b, l, c] = (x - mean[c]) / (std[c] + 1e-8)        c < 4,  pad rows included (they hold zeros, as the reference's
+//                                                            in-place normalisation of the padded array does)
+// (IEEE division and the reference's order of operations: bit-identical to the numpy result) and writes the mask
+// (1 = padding).  normalise = 0: copy / pad only (PhotoEventsDataset.collate leaves the standardisation to to_tensor).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void collate_photometry_kernel(const float *__restrict__ flat, const int64_t *__restrict__ offsets,
+                                                                 const int32_t *__restrict__ lens, const float *__restrict__ mean4,
+                                                                 const float *__restrict__ std4, float *__restrict__ out,
+                                                                 uint8_t *__restrict__ mask, int B, int L, int normalise) {
+    const int64_t n = (int64_t)B * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / L), l = (int)(i - (int64_t)b * L);
+        const int len = lens[b] < L ? lens[b] : L;
+        const bool valid = l < len;
+        const float *src = flat + (offsets[b] + l) * 7;
+        float *dst = out + i * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            float v = valid ? src[c] : 0.f;
+            if (normalise && c < 4) v = (v - mean4[c]) / (std4[c] + 1e-8f);
+            dst[c] = v;
+        }
+        mask[i] = valid ? 0 : 1;
+    }
+}
+
+extern "C" int ac_collate_photometry(const float *flat, const int64_t *offsets, const int32_t *lens, const float *mean4,
+                                     const float *std4, float *out, uint8_t *mask, int32_t B, int32_t L,
+                                     int32_t normalise, ac_stream_t stream) {
+    if (!flat || !offsets || !lens || !out || !mask || B <= 0 || L <= 0 || (normalise && (!mean4 || !std4))) return AC_EINVAL;
+    const int64_t n = (int64_t)B * L;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(collate_photometry_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, offsets, lens, mean4,
+                       std4, out, mask, B, L, normalise);
+    AC_CHECK_LAUNCH();
+    return AC_OK;
+}

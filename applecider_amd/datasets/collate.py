@@ -60,6 +60,42 @@ def collate_fused(batch: Sequence[tuple], mean: np.ndarray, std: np.ndarray, max
             np.asarray(labels, dtype=np.int64))
 
 
+def pack_ragged_photometry(photo: Sequence, max_len: int = None):
+    """Ragged light curves -> (flat f32 [sum, 7], offsets i64 [B], lens i32 [B], L): what the device-side collate takes.
+    No padding and no arithmetic on the host; L = max_len or the longest curve."""
+    arrs = [np.asarray(s, dtype=np.float32).reshape(-1, 7) for s in photo]
+    lens = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+    offsets = np.zeros(len(arrs), dtype=np.int64)
+    if len(arrs) > 1:
+        offsets[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    flat = np.concatenate(arrs, 0) if arrs else np.zeros((0, 7), np.float32)
+    if flat.shape[0] == 0:
+        flat = np.zeros((1, 7), np.float32)      # (a batch of empty curves still needs a valid pointer)
+    return flat, offsets, lens, int(max_len or lens.max())
+
+
+def collate_fused_device(batch: Sequence[tuple], mean, std, stager: "PinnedStager", max_len: int = None):
+    """collate_fused with the pad / truncate / standardise step ON THE DEVICE: the ragged photometry goes
+    over PCIe as it is (flat rows + offsets + lengths through the pinned stager), ac_collate_photometry builds the padded,
+    standardised [B, L, 7] tensor and the padding mask in HBM - bit-identical to the host arithmetic of `collate_fused`.
+    Returns the device tuple (photometry, photo_mask bool, metadata, images, spectra, labels)."""
+    from .. import _lib, hipops as H
+    photo, metadata, images, spectra, labels = zip(*batch)
+    flat, offsets, lens, L = pack_ragged_photometry(photo, max_len)
+    host = (flat, offsets, lens, np.asarray(mean, np.float32).reshape(4), np.asarray(std, np.float32).reshape(4),
+            np.stack([np.asarray(m, np.float32) for m in metadata]), np.stack([np.asarray(im, np.float32) for im in images]),
+            np.stack([np.asarray(sp, np.float32) for sp in spectra]), np.asarray(labels, dtype=np.int64))
+    d_flat, d_off, d_len, d_mean, d_std, d_meta, d_img, d_spec, d_lab = stager.stage(host)
+    B = len(batch)
+    out = torch.empty(B, L, 7, device=stager.device, dtype=torch.float32)
+    mask = torch.empty(B, L, device=stager.device, dtype=torch.uint8)
+    _lib.check(H._lib_().ac_collate_photometry(H._p(d_flat), H._p(d_off), H._p(d_len), H._p(d_mean), H._p(d_std), H._p(out),
+                                               H._p(mask), B, L, 1, H._stream()), "ac_collate_photometry")
+    for t in (d_flat, d_off, d_len, d_mean, d_std):      # consumed by a kernel on the current stream
+        t.record_stream(torch.cuda.current_stream(stager.device))
+    return out, mask.view(torch.bool), d_meta, d_img, d_spec, d_lab
+
+
 class PinnedStager:
     """Double-buffered pinned-host staging + async H2D on a copy stream.
 

@@ -333,12 +333,13 @@ def self_launch(args, argv) -> int:
     returns non-zero if any rank failed."""
     import subprocess
     cmd = launch_command([a for a in argv if a != "--dry-run-launch"], args.gpus, _free_port())
-    if args.dry_run_launch:
-        print(json.dumps({"launch": cmd}))
-        return 0
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL on this pool
     env.setdefault("OMP_NUM_THREADS", "4")
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd, "ranks": args.gpus,
+                          "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}))
+        return 0
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():

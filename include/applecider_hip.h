@@ -524,6 +524,17 @@ int ac_loss_fwd_bwd(const float *logits, const void *target, const float *alpha,
                     ac_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Photometry collate on the device (photo_dataset.py:117-152, Time2Vec.py:18-45, HyraxBaselineCLS.py:152-166): the
+ * ragged light curves arrive back to back, flat [sum of lengths, 7], sample b = rows offsets[b] .. offsets[b] + lens[b];
+ * every sample is padded with zeros / truncated to L rows, out [B, L, 7]; mask [B, L] = 1 on padding.  normalise != 0:
+ * channels 0..3 become (x - mean4[c]) / (std4[c] + 1e-8) on EVERY row, padding included - the reference standardises
+ * the padded array in place - with IEEE division: bit-identical to numpy's float32 result.
+ * ---------------------------------------------------------------------- */
+int ac_collate_photometry(const float *flat, const int64_t *offsets, const int32_t *lens, const float *mean4,
+                          const float *std4, float *out, uint8_t *mask, int32_t B, int32_t L, int32_t normalise,
+                          ac_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Masked pre-training step of MPTModel (HyraxBaselineCLS.py:226-319).
  * ac_mpt_mask: _mask_batch (:286-319) on the device.  x [B, L, 7] (in place: channels 2..6 of the
  * selected tokens become 0), pad [B, L] (1 = padding), masked [B, L] out.  Per light curve

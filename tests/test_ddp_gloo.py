@@ -177,23 +177,29 @@ def test_rank_offsets_dropout_seed():
     assert a != b and (b - a) % (1 << 64) != 0xD1B54A32D192ED03   # not just the counter step
 
 
-def test_bench_self_launch_dry_run():
-    """`python bench.py --gpus N` without WORLD_SIZE becomes the torch.distributed.run launcher."""
+@pytest.mark.parametrize("gpus", [4, 8])
+def test_bench_self_launch_dry_run(gpus):
+    """`python bench.py --gpus N` without WORLD_SIZE becomes the torch.distributed.run launcher: one rank per GPU,
+    rendezvous on 127.0.0.1, and dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0) in the ranks' environment even when the
+    caller's shell did not export it (without it RCCL fails with hipIpcGetMemHandle: invalid argument on this pool)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7",
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "7",
                           "--warmup", "2", "--dry-run-launch"], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr
-    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    cmd = plan["launch"]
+    assert plan["ranks"] == gpus and plan["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert cmd[1:3] == ["-m", "torch.distributed.run"]
-    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert f"--nproc-per-node={gpus}" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     i = cmd.index(os.path.join(root, "bench.py"))
-    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert cmd[i + 1:] == ["--gpus", str(gpus), "--steps", "7", "--warmup", "2"]
 
 
 def test_flat_optimizer_state_dict_round_trip_and_rehoming():

@@ -214,6 +214,22 @@ def _rccl_worker(port, q):
             assert len(streams) == 3 and main_key in streams, (streams, main_key)
             assert any(len(w) > 1 for _, w in log)
             assert launched_early >= 1, "no bucket was launched from the hooks while backward ran"
+            # SURVEY 8e / VERDICT r3 next #9: the overlap counts on the LATE layers' buckets leaving first - the
+            # 12 M weights of SpectraNet's last stage and ConvNeXt's stage 3 are ready long before the stems
+            names = {id(p_): n for n, p_ in m.m.named_parameters()}
+            order = {b: i for i, (b, _) in enumerate(log)}
+
+            def buckets(sub, only=False):
+                hit = {}
+                for i, p_ in enumerate(opt.fp.params):
+                    hit.setdefault(gb.bucket_of[i], []).append(sub in names[id(p_)])
+                return [b for b, v in hit.items() if (all(v) if only else any(v))]
+            for late, early in (("spectra_encoder.all_stages.4.", "spectra_encoder.all_stages.0."),
+                                ("image_tower.backbone.stages.3.", "image_tower.backbone.stem.")):
+                late_b, early_b = buckets(late, only=True), buckets(early)
+                assert late_b and early_b, (late, early)
+                assert max(order[b] for b in late_b) < min(order[b] for b in early_b), (late, early, log)
+            assert launched_early >= len(buckets("spectra_encoder.all_stages.4.", only=True))
             torch.cuda.synchronize()
             got = opt.fp.grad.clone()
             scale = want.abs().max().item()
