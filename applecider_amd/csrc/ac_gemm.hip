@@ -943,7 +943,65 @@ __device__ __forceinline__ bf16x8 frag_x3(const unsigned short *img, int colbase
     }
 }
 
-template <bool A_KC, bool B_KC, bool BATCH = false>
+// B operand from CACHED (hi, lo) planes (ac_gemm_desc.b_hi / b_lo: a weight matrix split once per optimizer step by
+// ac_split_bf16): a K tile is two 16-byte loads per plane and thread, written to the LDS images as they are - no split
+// arithmetic in the loop and half the operand bytes.  Every workgroup used to split the same weight tile again
+// (~3 VALU instructions per element per read; the kernel's small-K launches are bound by VALU issue and latency).
+template <bool KC>
+struct PlaneLoader {
+    const unsigned short *hi, *lo;
+    int64_t ld;
+    int outer_n, inner_n, origin, t;   // KC: outer = row (N), inner = K.  RC: outer = K, inner = column (N).
+
+    __device__ __forceinline__ void init(const ac_gemm_desc &d, int outer_extent, int inner_extent, int tile_origin, int tid) {
+        hi = (const unsigned short *)d.b_hi;
+        lo = (const unsigned short *)d.b_lo;
+        ld = d.ld_bpl;
+        outer_n = outer_extent;
+        inner_n = inner_extent;
+        origin = tile_origin;
+        t = tid;
+    }
+    __device__ __forceinline__ void load_raw(int kt, bf16x8 (&vh)[2], bf16x8 (&vl)[2], unsigned &mask) const {
+        mask = 0u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int64_t off;
+            bool in;
+            if (KC) {
+                const int r = origin + (t >> 2) + 64 * i, k = kt * BK + 8 * (t & 3);
+                in = r < outer_n && k < inner_n;
+                off = in ? (int64_t)r * ld + k : 0;
+            } else {
+                const int kr = kt * BK + (t >> 4) + 16 * i, c = origin + 8 * (t & 15);
+                in = kr < outer_n && c < inner_n;
+                off = in ? (int64_t)kr * ld + c : 0;
+            }
+            vh[i] = ac_gload<bf16x8>((const short *)hi + off);
+            vl[i] = ac_gload<bf16x8>((const short *)lo + off);
+            mask |= in ? (1u << i) : 0u;
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short *img_hi, unsigned short *img_lo, const bf16x8 (&vh)[2],
+                                          const bf16x8 (&vl)[2], unsigned mask) const {
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int off;
+            if (KC) {
+                const int r = (t >> 2) + 64 * i, c16 = t & 3;
+                off = r * 32 + ((c16 ^ ((r >> 2) & 3)) << 3);
+            } else {
+                off = ((t >> 4) + 16 * i) * X3_RC_PITCH + 8 * (t & 15);
+            }
+            const bool in = (mask >> i) & 1u;
+            *(bf16x8 *)(img_hi + off) = in ? vh[i] : zero;
+            *(bf16x8 *)(img_lo + off) = in ? vl[i] : zero;
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, bool BATCH = false, bool B_PL = false>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short *sm16 = reinterpret_cast<unsigned short *>(smem);
@@ -970,14 +1028,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
 
     Loader<A_KC> la;
     Loader<B_KC> lb;
+    PlaneLoader<B_KC> lp;
     if (A_KC)
         la.init(d.a, d.M, d.K, tm * BM, t);
     else
         la.init(d.a, d.K, d.M, tm * BM, t);
-    if (B_KC)
-        lb.init(d.b, d.N, d.K, tn * BN, t);
-    else
-        lb.init(d.b, d.K, d.N, tn * BN, t);
+    if constexpr (B_PL) {
+        if (B_KC)
+            lp.init(d, d.N, d.K, tn * BN, t);
+        else
+            lp.init(d, d.K, d.N, tn * BN, t);
+    } else {
+        if (B_KC)
+            lb.init(d.b, d.N, d.K, tn * BN, t);
+        else
+            lb.init(d.b, d.K, d.N, tn * BN, t);
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -1017,30 +1083,45 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
             acc[1][1] = AC_MFMA16(a1h, b1h, acc[1][1]);
         }
     };
-    auto stage_store = [&](unsigned short *stage, const f32x4 (&ra)[4], const f32x4 (&rb)[4], unsigned ma,
-                           unsigned mb) {
+    // B registers of one K tile: four fp32 float4s (split when stored) or, from cached planes, two 16-byte pieces of
+    // each plane (stored as they are)
+    struct BRegs {
+        f32x4 f[B_PL ? 1 : 4];
+        bf16x8 h[B_PL ? 2 : 1], l[B_PL ? 2 : 1];
+    };
+    auto load_b = [&](int kt, BRegs &r, unsigned &m) {
+        if constexpr (B_PL)
+            lp.load_raw(kt, r.h, r.l, m);
+        else
+            lb.load_raw(kt, r.f, m);
+    };
+    auto stage_store = [&](unsigned short *stage, const f32x4 (&ra)[4], const BRegs &rb, unsigned ma, unsigned mb) {
         store_x3<A_KC>(la, stage, stage + A_IMG, ra, ma);
-        store_x3<B_KC>(lb, stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb, mb);
+        if constexpr (B_PL)
+            lp.store(stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.h, rb.l, mb);
+        else
+            store_x3<B_KC>(lb, stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.f, mb);
     };
     unsigned short *S0 = sm16, *S1 = sm16 + STAGE;
-    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    f32x4 ra0[4], ra1[4];
+    BRegs rb0, rb1;
     unsigned ma0, mb0, ma1, mb1;
     la.load_raw(kt_begin, ra0, ma0);
-    lb.load_raw(kt_begin, rb0, mb0);
+    load_b(kt_begin, rb0, mb0);
     stage_store(S0, ra0, rb0, ma0, mb0);
     __syncthreads();
     la.load_raw(kt_begin + 1, ra0, ma0);
-    lb.load_raw(kt_begin + 1, rb0, mb0);
+    load_b(kt_begin + 1, rb0, mb0);
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         la.load_raw(kt + 2, ra1, ma1);
-        lb.load_raw(kt + 2, rb1, mb1);
+        load_b(kt + 2, rb1, mb1);
         __builtin_amdgcn_sched_barrier(0);
         compute(S0);
         stage_store(S1, ra0, rb0, ma0, mb0);
         __syncthreads();
         if (kt + 1 >= kt_end) break;
         la.load_raw(kt + 3, ra0, ma0);
-        lb.load_raw(kt + 3, rb0, mb0);
+        load_b(kt + 3, rb0, mb0);
         __builtin_amdgcn_sched_barrier(0);
         compute(S1);
         stage_store(S0, ra1, rb1, ma1, mb1);
@@ -1057,16 +1138,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
         store_tile(d, dseed, acc, tm * BM + wm * 64, tn * BN + wn * 64, li, lh);
 }
 
-template <bool A_KC, bool B_KC, bool BATCH = false>
+template <bool A_KC, bool B_KC, bool BATCH = false, bool B_PL = false>
 int launch_x3(const GemmParams &p, dim3 grid, hipStream_t stream) {
     constexpr int A_IMG = A_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int B_IMG = B_KC ? X3_KC_ELEMS : X3_RC_ELEMS;
     constexpr int LDS = 2 * (2 * A_IMG + 2 * B_IMG) * 2;   // two stages, bytes
     static_assert(LDS >= 4 * 2048 * 4, "the 16-byte epilogue parks 8 KB per wave in this buffer");
-    static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_x3_kernel<A_KC, B_KC, BATCH>,
+    static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_x3_kernel<A_KC, B_KC, BATCH, B_PL>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (attr != hipSuccess) return -(int)attr - 2000;
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, BATCH>), grid, dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, BATCH, B_PL>), grid, dim3(256), LDS, stream, p);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
@@ -1554,6 +1635,16 @@ static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int6
         return AC_OK;
     }
     if (d.math == AC_MATH_BF16X3) {
+        if (d.b_hi || d.b_lo) {
+            // B from cached planes: a plain row-major matrix, 16-byte aligned rows of whole 8-element pieces
+            const int inner = d.mode == AC_GEMM_NT ? d.K : d.N;
+            if (!d.b_hi || !d.b_lo || d.mode == AC_GEMM_TN || d.b.rows.r1 != 0 || d.b.goff || (d.ld_bpl % 8) ||
+                (inner % 8) || d.ld_bpl < inner)
+                return AC_EINVAL;
+            if (!ac_aligned16(d.b_hi) || !ac_aligned16(d.b_lo)) return AC_EALIGN;
+            if (d.mode == AC_GEMM_NT) return launch_x3<true, true, false, true>(p, grid, stream);
+            return launch_x3<true, false, false, true>(p, grid, stream);
+        }
         if (d.mode == AC_GEMM_NT) return launch_x3<true, true>(p, grid, stream);
         if (d.mode == AC_GEMM_NN) return launch_x3<true, false>(p, grid, stream);
         return launch_x3<false, false>(p, grid, stream);

@@ -134,7 +134,7 @@ def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) 
 def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
          ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
          accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0, c16=None, ld_c16=0,
-         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0, group=None):
+         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0, group=None, b_planes=None, ld_bpl=0):
     """group = [(a_ptr, b_ptr, c_ptr), ...] (device addresses): that many independent products of this shape in ONE
     launch (ac_gemm_grouped; a / b / c then only carry strides)."""
     d = GemmDesc()
@@ -152,6 +152,8 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     d.mask16, d.ld_mask16 = _p(mask16), ld_mask16
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.drop_step = _p(_STEP_DEV) if drop_p > 0.0 else None
+    if b_planes is not None:      # split-bf16: B from cached (hi, lo) planes (a weight: split once per optimizer step)
+        d.b_hi, d.b_lo, d.ld_bpl = _p(b_planes[0]), _p(b_planes[1]), int(ld_bpl)
     if group is not None:
         flat = [ptr for trip in group for ptr in trip]
         arr = (C.c_void_p * len(flat))(*flat)
@@ -233,7 +235,33 @@ def split16_T(t2d: torch.Tensor):
     return hi, lo
 
 
+def split16_into(src: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor):
+    _lib.check(_lib_().ac_split_bf16(_p(src), _p(hi), _p(lo), src.numel(), _stream()), "ac_split_bf16")
+
+
+def _plane_mirror(w):
+    """(hi, lo) views of `w` in the planes of its flat parameter buffer (optim.FlatParameters.refresh_mirrors: one
+    split launch per optimizer step for ALL parameters), or None when `w` does not live in such a buffer."""
+    ent = _mirror_owner.get(id(w))
+    if ent is None or ent[0]() is not w:
+        return None
+    fp = ent[1]()
+    if fp is None or fp.flat is None or not fp.flat.is_cuda:
+        return None
+    off, n = fp.offsets[ent[2]], w.numel()
+    if w.data_ptr() != fp.flat.data_ptr() + 4 * off or off % 8:
+        return None
+    if (fp.mirror_dirty or getattr(fp, "flat_hi", None) is None or fp.mirror_version != fp.flat._version
+            or fp.mirror_pver[ent[2]] != w._version or getattr(fp, "mirror_epoch", -1) != _MATH_EPOCH):
+        fp.refresh_mirrors()
+    return fp.flat_hi[off:off + n].view(w.shape), fp.flat_lo[off:off + n].view(w.shape)
+
+
 def split16_w(w):
+    if x3_mode():
+        m = _plane_mirror(w)
+        if m is not None:
+            return m
     return _cached(w, "s", split16)
 
 
@@ -375,9 +403,10 @@ def ensure_mirrors(fp):
     """Refresh the bf16 parameter mirrors now (on the current stream) if they are stale: callers that
     fan work out over several streams do this before the fork, so that no branch triggers the lazy
     refresh while another is already reading the mirrors."""
-    if fp is None or fp.flat is None or not fp.flat.is_cuda or not bf16_operands():
+    if fp is None or fp.flat is None or not fp.flat.is_cuda or not (bf16_operands() or x3_mode()):
         return
-    stale = (fp.mirror_dirty or fp.flat16 is None or fp.mirror_version != fp.flat._version
+    have = fp.flat_hi if x3_mode() else fp.flat16
+    stale = (fp.mirror_dirty or have is None or fp.mirror_version != fp.flat._version
              or getattr(fp, "mirror_epoch", -1) != _MATH_EPOCH)
     if not stale:
         stale = any(v != p._version for v, p in zip(fp.mirror_pver, fp.params))
@@ -746,6 +775,18 @@ def _defer_weight_grad(Nw, Kw, rows, g, x2, dw, wp):
         torch.autograd.Variable._execution_engine.queue_callback(flush_weight_gradients)
 
 
+_PLANE_B = True   # tests / A-B: False = nn.Linear products split their weight operand on the fly
+
+
+def _wplanes(wparam, N: int, K: int) -> dict:
+    """gemm() keywords that feed a weight [N, K] to a split-bf16 product as cached (hi, lo) planes (B operand of the
+    NT forward product and of the NN input-gradient product)."""
+    if not (_PLANE_B and x3_mode() and K % 8 == 0 and tuple(wparam.shape) == (N, K) and wparam.is_contiguous()
+            and wparam.dtype == torch.float32):
+        return {}
+    return {"b_planes": split16_w(wparam), "ld_bpl": K}
+
+
 # --------------------------------------------------------------------------- Linear
 class _Linear(Function):
     """y = [drop](act(x @ w.T + b) [* colscale]) [+ residual]   (nn.Linear + fused epilogue).
@@ -756,6 +797,7 @@ class _Linear(Function):
     def forward(ctx, x, w, b, act, residual, colscale, drop_p=0.0):
         ctx.x16only = _is16only(x)   # producer handed the activation over in bf16 only
         x = _chk(x, "x", allow16=True)
+        wparam = w
         w = _chk(w, "w")
         N, K = w.shape
         x2 = x.reshape(-1, K)
@@ -793,13 +835,13 @@ class _Linear(Function):
                 # sums the slabs in order and applies bias / layer scale / skip (which need the complete sum)
                 part = torch.empty(split, M, N, device=x.device, dtype=torch.float32)
                 gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(part), N), accumulate=3,
-                     split_k=split)
+                     split_k=split, **_wplanes(wparam, N, K))
                 _lib.check(_lib_().ac_splitk_reduce(_p(part), split, _p(b), _p(pre), _p(colscale), _p(residual),
                                                     _p(y), M, N, _stream()), "ac_splitk_reduce")
             else:
                 gemm(AC_GEMM_NT, M, N, K, mat(_p(x2), K), mat(_p(w), K), mat(_p(y), N), bias=b, act=act,
                      pre_out=pre, ld_pre=N, colscale=colscale, residual=residual, ld_res=N,
-                     drop_p=ctx.drop_p, drop_seed=ctx.drop_seed)
+                     drop_p=ctx.drop_p, drop_seed=ctx.drop_seed, **_wplanes(wparam, N, K))
         if act == ACT_RELU and ROUTING_TAP is not None:
             _tap("relu", pre if pre is not None else y)     # (sign pattern = the gates; tests: ROUTING_TAP)
         ctx.act, ctx.has_res = act, residual is not None
@@ -886,9 +928,9 @@ class _Linear(Function):
                 if split > 1:
                     dx.zero_()
                     gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), accumulate=2,
-                         split_k=split)
+                         split_k=split, **_wplanes(ctx.wp, N, K))
                 else:
-                    gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K))
+                    gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), **_wplanes(ctx.wp, N, K))
             if not _is16only(dx):
                 dx = dx.reshape(ctx.shape_x)
             elif dx.shape != ctx.shape_x:

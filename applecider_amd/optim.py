@@ -37,6 +37,7 @@ class FlatParameters:
         self.flat: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
         self.flat16 = self.flatT16 = None
+        self.flat_hi = self.flat_lo = None
         self.mirror_dirty, self.mirror_version = True, -1
         self.offsets: List[int] = []
         self.group_ranges: List[tuple] = []
@@ -73,12 +74,25 @@ class FlatParameters:
                 p.grad = grad[off:off + n].view(p.shape)
         self.flat, self.grad, self.offsets, self.group_ranges = flat, grad, offsets, ranges
         self.flat16 = self.flatT16 = None
+        self.flat_hi = self.flat_lo = None
         self.mirror_dirty, self.mirror_version = True, -1
         if flat.is_cuda:
             H.register_mirror(self)
 
     def refresh_mirrors(self):
-        """bf16 copies of all parameters (and the transposes of the 2-D ones) in two launches."""
+        """16-bit operand copies of ALL parameters, made once per optimizer step.  bf16 / f16 modes: casts (and the
+        transposes of the 2-D ones) in two launches.  Split-bf16 mode: the (hi, lo) planes of the whole buffer in ONE
+        launch (ac_split_bf16) - every product that takes a weight as its B operand reads views of them
+        (hipops.split16_w: the conv taps of SpectraNet, the plane-fed nn.Linear products)."""
+        if H.x3_mode():
+            if getattr(self, "flat_hi", None) is None or self.flat_hi.dtype != H._H16:
+                self.flat_hi = torch.empty(self.flat.numel(), device=self.flat.device, dtype=H._H16)
+                self.flat_lo = torch.empty_like(self.flat_hi)
+            H.split16_into(self.flat, self.flat_hi, self.flat_lo)
+            self.mirror_dirty, self.mirror_version = False, self.flat._version
+            self.mirror_epoch = H._MATH_EPOCH
+            self.mirror_pver = [p._version for p in self.params]
+            return
         if self.flat16 is None or self.flat16.dtype != H._H16:
             self.flat16 = torch.empty(self.flat.numel(), device=self.flat.device, dtype=H._H16)
             self.flatT16 = torch.empty_like(self.flat16)

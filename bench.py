@@ -312,6 +312,34 @@ def measure_ceilings(H, dev):
     return out
 
 
+def parse_rccl_log(path: str) -> dict:
+    """What rank 0's NCCL_DEBUG=INFO log says about the communicator: algorithm / protocol choices of the collectives
+    (TUNING lines), transports of the channels (P2P / SHM / NET), rings / trees.  Best effort: the format is RCCL's."""
+    import collections
+    import re
+    algo, via, misc = collections.Counter(), collections.Counter(), {}
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError as e:
+        return {"log": path, "error": str(e)}
+    for ln in lines:
+        m = re.search(r"(AllReduce|Broadcast|AllGather|ReduceScatter)[^\n]*?[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+)[^\n]*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)", ln)
+        if m:
+            algo[f"{m.group(1)} algo {m.group(2)} proto {m.group(3)}"] += 1
+        m = re.search(r"\bvia\s+([A-Za-z0-9/_]+)", ln)
+        if m:
+            via[m.group(1)] += 1
+        m = re.search(r"(\d+) coll channels.*?(\d+) p2p channels", ln)
+        if m:
+            misc["coll_channels"], misc["p2p_channels"] = int(m.group(1)), int(m.group(2))
+        if "Connected all rings" in ln:
+            misc["rings_connected"] = True
+        if "Connected all trees" in ln:
+            misc["trees_connected"] = True
+    return {"log_lines": len(lines), "collective_choices": dict(algo.most_common(8)), "transports": dict(via.most_common(6)),
+            **misc}
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as sk:
@@ -578,6 +606,14 @@ def main():
     from applecider_amd.models.applecider import AppleCider
     from applecider_amd.synthetic import make_batch
 
+    rccl_log = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0
+            and not args.rehearse_one_gpu and "NCCL_DEBUG" not in os.environ):
+        # rank 0 records which algorithm / protocol / transports RCCL picks for the gradient all-reduce (SURVEY 8e:
+        # "verify with NCCL_DEBUG=INFO"): a few hundred log lines into a file, parsed into the JSON line below
+        import tempfile
+        rccl_log = os.path.join(tempfile.mkdtemp(prefix="applecider_rccl_"), "rank0.log")
+        os.environ.update({"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,GRAPH,TUNING", "NCCL_DEBUG_FILE": rccl_log})
     if args.rehearse_one_gpu:
         os.environ["LOCAL_RANK"] = "0"
         rank, local, world = ddp.init_from_env(backend="gloo")
@@ -708,6 +744,24 @@ def main():
         barrier()
         timer.enabled = False
         model.branch_streams = was_streams
+
+    # kernel launches of ONE step (torch.profiler device events): the library's own and what is left of ATen's small
+    # add / fill / copy launches
+    launches = None
+    if world == 1 and not profiler_attached():
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+            names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+            aten = [n for n in names if "at::native" in n or n.startswith("void at::")]
+            runtime = [n for n in names if "rocclr" in n or n.startswith("Memcpy") or n.startswith("Memset")]
+            launches = {"total": len(names), "aten": len(aten), "runtime_copy_fill": len(runtime),
+                        "library": len(names) - len(aten) - len(runtime),
+                        "how": "torch.profiler device events of one eager step after the timed region"}
+        except Exception as e:      # a profiler that is unavailable must not cost the bench line
+            launches = {"error": str(e)[:200]}
 
     fast = None
     if args.math != "bf16" and not args.no_fast_mode:
@@ -864,6 +918,8 @@ def main():
                    "encoder_streams": 3 if model.branch_streams else 1},
         "roofline": roofline,
     }
+    if launches is not None:
+        out["launches_per_step"] = launches
     if "freqconv" in ks:
         d = ks["freqconv"]
         out["frequency_domain_convs"] = {
@@ -947,6 +1003,8 @@ def main():
         res["value"] = round(res["value"], 3)
         res["ms_per_step"] = round(res["ms_per_step"], 1)
         out["cpu_baseline"] = res
+    if rccl_log is not None:
+        out["rccl"] = parse_rccl_log(rccl_log)
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -137,6 +137,12 @@ typedef struct ac_gemm_desc {
     float drop_p;         /* 0: no dropout */
     uint64_t drop_seed;
     const uint64_t *drop_step; /* nullable DEVICE counter mixed into drop_seed (see ac_step_advance) */
+    /* AC_MATH_BF16X3, NT / NN, one product (not batched / grouped), nullable: the B operand as CACHED (hi, lo) bf16
+       planes (ac_split_bf16 of the same matrix, e.g. a weight split once per optimizer step) - plain row-major with
+       row pitch ld_bpl elements (% 8 == 0, rows 16-byte aligned, inner extent % 8 == 0).  The kernel then reads B
+       from the planes (b.ptr is ignored): no split arithmetic per read, half the operand bytes. */
+    const void *b_hi, *b_lo;
+    int64_t ld_bpl;
 } ac_gemm_desc;
 
 int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);

@@ -1114,3 +1114,46 @@ def test_grouped_weight_gradients_equal_separate_launches(dev, mode):
             close(a, b, tol=2e-6, name=f"grad {i}")
     finally:
         H.set_math("f32")
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 1536, 384), (1000, 96, 384), (66048, 512, 128), (260, 40, 72), (512, 384, 3072)])
+def test_linear_with_plane_fed_weight_equals_on_the_fly_split(dev, M, N, K):
+    """Split-bf16 nn.Linear products read their weight as cached (hi, lo) planes (ac_gemm_desc.b_hi / b_lo: split once
+    per optimizer step instead of in every workgroup's K loop).  The planes hold exactly what the on-the-fly split
+    computes, so forward and input gradient are BIT-IDENTICAL to the fp32-operand form - ragged M / N, the split-K
+    forms (slabs forward, atomics backward) included; a parameter living in a flat buffer takes its planes from the
+    buffer's one-launch split."""
+    from applecider_amd import hipops as H
+    from applecider_amd.optim import FlatAdam
+    H.set_math("bf16x3")
+    try:
+        torch.manual_seed(M + N)
+        x0 = torch.randn(M, K, device=dev)
+        go = torch.randn(M, N, device=dev)
+        res = {}
+        for planes in (True, False, "flat"):
+            w = torch.nn.Parameter(torch.randn(N, K, generator=torch.Generator().manual_seed(5)).to(dev) / math.sqrt(K))
+            b = torch.nn.Parameter(torch.randn(N, generator=torch.Generator().manual_seed(6)).to(dev))
+            if planes == "flat":
+                opt = FlatAdam([{"params": [w, b]}], lr=1e-3)
+                opt.prepare()
+                assert H._plane_mirror(w) is not None
+            H._PLANE_B = bool(planes)
+            H.clear_step_cache()
+            try:
+                x = x0.clone().requires_grad_()
+                y = H.linear(x, w, b, act="gelu" if N % 2 == 0 and M != 512 else None)
+                y.backward(go)
+                torch.cuda.synchronize()
+            finally:
+                H._PLANE_B = True
+            res[planes] = (y.detach().clone(), x.grad.clone())
+        split_bwd = H._small_grid_split(M, K, N) > 1           # atomics: equal to rounding, not bit for bit
+        for tag in (True, "flat"):
+            assert torch.equal(res[tag][0], res[False][0]), f"forward differs ({tag})"
+            if split_bwd:
+                close(res[tag][1], res[False][1], tol=2e-6, name="dx")
+            else:
+                assert torch.equal(res[tag][1], res[False][1]), f"dx differs ({tag})"
+    finally:
+        H.set_math("f32")
