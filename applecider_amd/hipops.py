@@ -2204,9 +2204,7 @@ class _ConvGroup1d(Function):
             pooled = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.float32)
             pidx = torch.empty(B, L // 4, Cpw, device=dev, dtype=torch.uint8)
             wh, wl = split16_w(pw_w)
-            _lib.check(_lib_().ac_spectail_fwd(_p(ycat), _p(ln_gamma), _p(ln_beta), ln_eps, _p(wh), _p(wl), _p(pw_b),
-                                               _p(mean), _p(rstd), _p(pooled), _p(pidx), rows, Ncat, Cpw, _stream()),
-                       "ac_spectail_fwd")
+            spectail_fwd(ycat, ln_gamma, ln_beta, ln_eps, wh, wl, pw_b, mean, rstd, pooled, pidx, rows, Ncat, Cpw)
             _tap("pool4", pidx)
             ctx.tail, ctx.pw = True, (pw_w, pw_b)
             ctx.save_for_backward(xpad, *ws, ycat, mean, rstd, ln_gamma, ln_beta, pidx, pw_w)
@@ -2268,9 +2266,7 @@ class _ConvGroup1d(Function):
                 if ctx.needs_input_grad[6]:
                     wsink = _sink(ctx.pw[0])
                     dpw_w = wsink if wsink is not None else torch.zeros(Cpw, Ncat, device=dev, dtype=torch.float32)
-                    _lib.check(_lib_().ac_spectail_bwd_dw(_p(ycat), _p(mean), _p(rstd), _p(ln_gamma), _p(ln_beta),
-                                                          _p(dpool), _p(pidx), _p(dpw_w), rows, Ncat, Cpw, _stream()),
-                               "ac_spectail_bwd_dw")
+                    spectail_bwd_dw(ycat, mean, rstd, ln_gamma, ln_beta, dpool, pidx, dpw_w, rows, Ncat, Cpw)
                     if wsink is not None:
                         dpw_w = None
                         _grad_written(ctx.pw[0])
@@ -2333,10 +2329,8 @@ class _ConvGroup1d(Function):
                 dpre, out16 = torch.empty(B, L, Ncat, device=dev, dtype=torch.float32), None
             if ctx.tail:
                 wth, wtl = split16_wT(pw_w)
-                _lib.check(_lib_().ac_spectail_bwd_dx(_p(ycat), _p(mean), _p(rstd), _p(ln_gamma), _p(ln_beta), _p(dpool),
-                                                      _p(pidx), _p(wth), _p(wtl), _p(out16), _p(lo16), seg[0], seg[1],
-                                                      seg[2], _p(dgam), _p(dbet), _p(bias_sums), B * L, Ncat,
-                                                      pw_w.shape[0], _stream()), "ac_spectail_bwd_dx")
+                spectail_bwd_dx(ycat, mean, rstd, ln_gamma, ln_beta, dpool, pidx, wth, wtl, out16, lo16, seg, dgam, dbet,
+                                bias_sums, B * L, Ncat, pw_w.shape[0])
                 if not (planes1 or planes_direct):
                     dpre = (both[0].float() + both[1].float()).reshape(B, L, Ncat)
             else:
@@ -2534,6 +2528,23 @@ class _ConvGroup1d(Function):
 
 
 _FUSED_TAIL = True   # tests / A-B: False = LayerNorm, 1x1 conv and MaxPool(4) as separate kernels everywhere
+
+
+# the three tail kernels behind module-level names (bench.py brackets them with HIP events)
+def spectail_fwd(ycat, gamma, beta, eps, wh, wl, bias, mean, rstd, pooled, pidx, rows, K, N):
+    _lib.check(_lib_().ac_spectail_fwd(_p(ycat), _p(gamma), _p(beta), eps, _p(wh), _p(wl), _p(bias), _p(mean), _p(rstd),
+                                       _p(pooled), _p(pidx), rows, K, N, _stream()), "ac_spectail_fwd")
+
+
+def spectail_bwd_dx(ycat, mean, rstd, gamma, beta, dpool, pidx, wth, wtl, out_hi, out_lo, seg, dgam, dbet, dxsum, rows, K, N):
+    _lib.check(_lib_().ac_spectail_bwd_dx(_p(ycat), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dpool), _p(pidx), _p(wth),
+                                          _p(wtl), _p(out_hi), _p(out_lo), seg[0], seg[1], seg[2], _p(dgam), _p(dbet),
+                                          _p(dxsum), rows, K, N, _stream()), "ac_spectail_bwd_dx")
+
+
+def spectail_bwd_dw(ycat, mean, rstd, gamma, beta, dpool, pidx, dw, rows, K, N):
+    _lib.check(_lib_().ac_spectail_bwd_dw(_p(ycat), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dpool), _p(pidx), _p(dw),
+                                          rows, K, N, _stream()), "ac_spectail_bwd_dw")
 
 
 def tail_covered(B: int, L: int, Cin: int, Cout: int, nk: int = 3) -> bool:

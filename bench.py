@@ -190,6 +190,27 @@ class KernelTimer:
                                  lambda mode, M, N, K, a, b, c, batch, *r, **kw:
                                  (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + (2 if kw.get("accumulate") else 1) * M * N)))
 
+    def wrap_spectail(self, H):
+        """Fused tail of the pooled SpectraNet blocks (csrc/ac_tail.hip): HBM-bound by construction - algorithmic bytes =
+        the concatenated conv outputs read once (fp32) + the pooled rows / arg-max / statistics, and for the
+        input-gradient kernel the (hi, lo) planes written once (as many bytes as fp32).  FLOP = the 1x1 conv's."""
+        def bracket(orig, work):
+            def timed(*a):
+                if not self.enabled:
+                    return orig(*a)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig(*a)
+                e.record()
+                fl, by = work(*a)
+                self.records.setdefault("spectail", []).append((s, e, fl, by))
+                return r
+            return timed
+        small = lambda rows, N: rows // 4 * N * 5.0 + rows * 8.0
+        H.spectail_fwd = bracket(H.spectail_fwd, lambda *a: (2.0 * a[11] * a[12] * a[13], 4.0 * a[11] * a[12] + small(a[11], a[13])))
+        H.spectail_bwd_dx = bracket(H.spectail_bwd_dx, lambda *a: (2.0 * a[15] * a[16] * a[17], 8.0 * a[15] * a[16] + small(a[15], a[17])))
+        H.spectail_bwd_dw = bracket(H.spectail_bwd_dw, lambda *a: (2.0 * a[8] * a[9] * a[10], 4.0 * a[8] * a[9] + small(a[8], a[10])))
+
     def wrap_dwconv(self, H):
         lib = H._lib_()
         orig = lib.ac_dwconv7x7_fwd
@@ -660,6 +681,7 @@ def main():
     timer.wrap_conv_window(H)
     timer.wrap_conv_wgrad(H)
     timer.wrap_fft(H)
+    timer.wrap_spectail(H)
     timer.wrap_dwconv(H)
 
     for _ in range(args.warmup):
@@ -804,8 +826,10 @@ def main():
     ks = timer.summary(peak * 1e12, HBM_PEAK_GBS * 1e9)
     timed_steps, args_steps_saved = args.steps, args.steps
     args.steps = roof_steps   # the per-step figures below refer to the roofline pass
-    gemms = {k: v for k, v in ks.items() if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft")}
-    kernel_of = {"conv1d_window": "conv1d_window_x3_kernel" if args.math == "bf16x3" else "conv1d_window_kernel",
+    gemms = {k: v for k, v in ks.items()
+             if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft") or k == "spectail"}
+    kernel_of = {"spectail": "tail_fwd_kernel / tail_bwd_dx_kernel / tail_bwd_dw_kernel",
+                 "conv1d_window": "conv1d_window_x3_kernel" if args.math == "bf16x3" else "conv1d_window_kernel",
                  "conv1d_wgrad": "conv1d_wgrad_kernel", "fft_rows": "fft_rows_fwd_kernel / fft_rows_inv_kernel",
                  "fft_taps": "fft_taps_fwd_kernel / fft_taps_inv_kernel",
                  "fft_prod": "gemm_x3_kernel<batched>" if args.math == "bf16x3" else "gemm_f32_kernel<batched>"}
@@ -874,6 +898,8 @@ def main():
             want = "gemm_x3_kernel" if args.math == "bf16x3" else "gemm_f32_kernel"
         if dom_name in ("fft_rows", "fft_taps"):
             want = dom_name + "_"
+        if dom_name == "spectail":
+            want = "tail_"
         if args.math == "bf16x3" and dom_name == "conv1d_window":
             want = "conv1d_window_x3"
         hits = [v for k, v in pmc.items() if want and want in k and isinstance(v, dict)
@@ -900,7 +926,8 @@ def main():
     if ran_pass and args.events_in_timed_region:
         roofline["timed_region_overlapped"] = {
             k: {"launches": v["launches"], "sum_of_launch_ms_per_step": round(v["ms"] / timed_steps, 3)}
-            for k, v in ks_timed.items() if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft")}
+            for k, v in ks_timed.items()
+            if k.startswith("gemm") or k.startswith("conv1d") or k.startswith("fft") or k == "spectail"}
     out = {
         "metric": "multimodal samples/sec/GPU (fwd+bwd) at batch 512; 1->8 GPU scaling",
         "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",

@@ -40,3 +40,15 @@ def full():
 print(mode, "full step, one stream   ", round(timeit(full), 2), "ms", flush=True)
 m.branch_streams = True
 print(mode, "full step, three streams", round(timeit(full), 2), "ms", flush=True)
+# A/B of the stream layout (round 4): both side branches on ONE side stream; side streams at high priority
+import applecider_amd.models.applecider as AC
+st = m._streams(dev)
+orig = list(st)
+m._branch_streams = [st[0], st[0]]
+print(mode, "full step, two streams (image + photometry share one)", round(timeit(full), 2), "ms", flush=True)
+lo, hi = torch.cuda.Stream.priority_range()
+m._branch_streams = [torch.cuda.Stream(device=dev, priority=hi), torch.cuda.Stream(device=dev, priority=hi)]
+H.register_side_streams(m._branch_streams)
+print(mode, "full step, three streams, side branches at high priority", round(timeit(full), 2), "ms", flush=True)
+m._branch_streams = orig
+print(mode, "full step, three streams (again)", round(timeit(full), 2), "ms", flush=True)
