@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
         ("c16", C.c_void_p), ("ld_c16", C.c_int64),
         ("mask16", C.c_void_p), ("ld_mask16", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_step", C.c_void_p),
-        ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("ld_bpl", C.c_int64),
+        ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("ld_bpl", C.c_int64), ("colsum", C.c_void_p),
     ]
 
 

@@ -194,8 +194,8 @@ __device__ __forceinline__ void store_tile_slab(const ac_gemm_desc &d, const f32
 // LDS and re-reads it row-major, so every lane handles 4 consecutive columns of one row: bias /
 // aux / residual come in as float4 and C goes out as float4 — 4x fewer memory instructions than the
 // one-float-per-lane accumulator layout (the memory-bound small-K products were store-issue bound).
-__device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
-                                             int64_t caddr) {
+__device__ __forceinline__ f32x4 epilogue_vec(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
+                                              int64_t caddr) {
     v *= d.alpha;
     if (d.bias) v += *(const f32x4 *)(d.bias + n);
     if (d.pre_out) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
@@ -228,12 +228,13 @@ __device__ __forceinline__ void epilogue_vec(const ac_gemm_desc &d, uint64_t dse
         h.x = epi_bf16(v[0]); h.y = epi_bf16(v[1]); h.z = epi_bf16(v[2]); h.w = epi_bf16(v[3]);
         *(ushort4 *)((unsigned short *)d.c16 + (int64_t)m * d.ld_c16 + inner_off(d.c.goff, n)) = h;
     }
-    if (!d.c.ptr) return;
+    if (!d.c.ptr) return v;
     f32x4 *c = (f32x4 *)((float *)d.c.ptr + caddr);
     if (d.accumulate == 1)
         *c += v;
     else
         *c = v;
+    return v;
 }
 
 // Compile-time epilogue variants.  The generic epilogue_vec tests a dozen descriptor fields per
@@ -245,7 +246,8 @@ enum : unsigned {
     E_BIAS = 1u, E_PRE = 2u, E_GELU = 4u, E_RELU = 8u, E_DGELU = 16u, E_MASK16 = 32u, E_CSCALE = 64u,
     E_DROP = 128u, E_RES = 256u, E_C16 = 512u, E_C32 = 1024u, E_ACC = 2048u,
     E_FAST = 4096u,  // bf16 / split-bf16 math modes: rational erf inside GELU / GELU'
-    E_GOFF = 8192u   // C columns through the offset table (conv outputs scattered into the cat buffer)
+    E_GOFF = 8192u,  // C columns through the offset table (conv outputs scattered into the cat buffer)
+    E_DRELU = 16384u // v *= (aux > 0): ReLU' of the layer whose hidden gradient this product forms
 };
 #define AC_EPI_VARIANTS(X)                                                                      \
     X(0, E_C32) X(1, E_C32 | E_BIAS) X(2, E_C16 | E_BIAS | E_GELU | E_PRE)                       \
@@ -258,12 +260,13 @@ enum : unsigned {
     X(19, E_C32 | E_BIAS | E_GOFF) X(20, E_C32 | E_GOFF) X(21, E_C16 | E_BIAS | E_GOFF)                    \
     X(22, E_C32 | E_BIAS | E_GELU | E_PRE) X(23, E_C32 | E_BIAS | E_RELU)                                 \
     X(24, E_C32 | E_BIAS | E_RELU | E_PRE | E_RES) X(25, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES)       \
-    X(26, E_C32 | E_BIAS | E_GELU | E_PRE | E_FAST) X(27, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES | E_FAST)
+    X(26, E_C32 | E_BIAS | E_GELU | E_PRE | E_FAST) X(27, E_C32 | E_BIAS | E_GELU | E_PRE | E_RES | E_FAST)   \
+    X(28, E_C32 | E_DGELU | E_FAST) X(29, E_C32 | E_DGELU) X(30, E_C32 | E_DRELU) X(31, E_C32 | E_DRELU | E_DROP)
 constexpr int EPI_GENERIC = 255;
 
 template <unsigned F>
-__device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
-                                               const f32x4 &bias4, const f32x4 &cs4, int64_t ccol) {
+__device__ __forceinline__ f32x4 epilogue_vec_t(const ac_gemm_desc &d, uint64_t dseed, int m, int n, f32x4 v,
+                                                const f32x4 &bias4, const f32x4 &cs4, int64_t ccol) {
     v *= d.alpha;
     if constexpr (F & E_BIAS) v += bias4;  // per-column vectors are loaded once per tile
     if constexpr (F & E_PRE) *(f32x4 *)(d.pre_out + (int64_t)m * d.ld_pre + n) = v;
@@ -279,6 +282,11 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, uint64_t d
         const f32x4 a = *(const f32x4 *)(d.aux + (int64_t)m * d.ld_aux + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= (F & E_FAST) ? ac_gelu_grad_fast(a[j]) : ac_gelu_grad(a[j]);
+    }
+    if constexpr (F & E_DRELU) {
+        const f32x4 a = *(const f32x4 *)(d.aux + (int64_t)m * d.ld_aux + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
     }
     if constexpr (F & E_MASK16) {
         const ushort4 k = *(const ushort4 *)((const unsigned short *)d.mask16 + (int64_t)m * d.ld_mask16 + n);
@@ -305,6 +313,7 @@ __device__ __forceinline__ void epilogue_vec_t(const ac_gemm_desc &d, uint64_t d
         f32x4 *c = (f32x4 *)((float *)d.c.ptr + (int64_t)m * d.c.rows.s3 + ((F & E_GOFF) ? ccol : (int64_t)n));
         if constexpr (F & E_ACC) *c += v; else *c = v;
     }
+    return v;
 }
 
 template <int VAR>
@@ -314,7 +323,7 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, uint64_t
     const int rsub = lane >> 4, c4 = 4 * (lane & 15);
     const int n = col_base + c4;
     const int64_t coff = (d.c.goff != nullptr && n < d.N) ? inner_off(d.c.goff, n) : (int64_t)n;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cs4 = {1.f, 1.f, 1.f, 1.f};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cs4 = {1.f, 1.f, 1.f, 1.f}, csum = {0.f, 0.f, 0.f, 0.f};
     if (VAR != EPI_GENERIC && n < d.N) {
         if (d.bias) bias4 = *(const f32x4 *)(d.bias + n);
         if (d.colscale) cs4 = *(const f32x4 *)(d.colscale + n);
@@ -334,16 +343,31 @@ __device__ __forceinline__ void store_tile_vec_t(const ac_gemm_desc &d, uint64_t
             const f32x4 v = *(const f32x4 *)(wbuf + r * 64 + c4);
             const int m = row_base + sa * 32 + r;
             if (m < d.M && n < d.N) {
+                f32x4 o;
                 if constexpr (VAR == EPI_GENERIC) {
-                    epilogue_vec(d, dseed, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
+                    o = epilogue_vec(d, dseed, m, n, v, ac_rowaddr(d.c.rows, m) + coff);
                 } else {
-#define AC_EPI_CALL(I, F) if constexpr (VAR == I) epilogue_vec_t<(F)>(d, dseed, m, n, v, bias4, cs4, coff);
+#define AC_EPI_CALL(I, F) if constexpr (VAR == I) o = epilogue_vec_t<(F)>(d, dseed, m, n, v, bias4, cs4, coff);
                     AC_EPI_VARIANTS(AC_EPI_CALL)
 #undef AC_EPI_CALL
                 }
+                csum += o;
             }
         }
     });
+    // ac_gemm_desc.colsum: column sums of what this wave stored (its 64 rows) -> one atomic per column.  The bias
+    // gradient of the layer whose activation backward the epilogue applied (dact): no separate pass over the tensor.
+    if (d.colsum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            csum[j] += __shfl_xor(csum[j], 16, 64);
+            csum[j] += __shfl_xor(csum[j], 32, 64);
+        }
+        if (rsub == 0 && n < d.N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(d.colsum + n + j, csum[j]);
+        }
+    }
 }
 
 __device__ __forceinline__ void store_tile_vec(const ac_gemm_desc &d, uint64_t dseed, int variant,
@@ -1456,6 +1480,7 @@ int epilogue_variant(const ac_gemm_desc &d, int accumulate) {
     else if (d.act == AC_ACT_RELU) f |= E_RELU;
     else if (d.act != AC_ACT_NONE) return EPI_GENERIC;
     if (d.dact == AC_ACT_GELU || d.dact == AC_ACT_GELU_FAST) f |= E_DGELU;
+    else if (d.dact == AC_ACT_RELU) f |= E_DRELU;
     else if (d.dact != AC_ACT_NONE) return EPI_GENERIC;
     if (d.mask16) f |= E_MASK16;
     if (d.colscale) f |= E_CSCALE;
@@ -1598,6 +1623,7 @@ static int gemm_run(const ac_gemm_desc *dp, ac_stream_t stream_, int batch, int6
     if (d.split_k > 1 && (d.bias || d.pre_out || d.act || d.dact || d.residual)) return AC_EINVAL;
     p.vec_epi = slabs ? 3 : vec_epilogue_ok(p.d, p.d.accumulate);
     p.epi_var = slabs ? EPI_GENERIC : epilogue_variant(p.d, p.d.accumulate);
+    if (d.colsum && (p.vec_epi != 1 || d.split_k != 1 || !d.c.ptr || batch > 1 || grp)) return AC_EINVAL;
     p.tiles_m = (d.M + BM - 1) / BM;
     p.tiles_n = (d.N + BN - 1) / BN;
     p.nkt = (d.K + BK - 1) / BK;

@@ -163,14 +163,6 @@ class GradBuckets:
 
     def _make_hook(self, idx: int):
         def hook(_param):
-            # a weight gradient that waits for its grouped launch (hipops._defer_weight_grad) is not in the buffer yet:
-            # its report comes from the launch (_on_sink), not from autograd's hook
-            try:
-                from . import hipops as H
-                if H.grad_is_deferred(_param):
-                    return
-            except Exception:  # CPU-only unit tests without the shared library
-                pass
             self._report(idx)
         return hook
 

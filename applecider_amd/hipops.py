@@ -134,7 +134,7 @@ def mat(ptr, s3=0, r1=0, r2=0, s1=0, s2=0, goff: Optional[torch.Tensor] = None) 
 def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_out=None,
          ld_pre=0, dact=ACT_NONE, aux=None, ld_aux=0, colscale=None, residual=None, ld_res=0,
          accumulate=0, split_k=1, alpha=1.0, force_simple=0, math=None, tile=0, c16=None, ld_c16=0,
-         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0, group=None, b_planes=None, ld_bpl=0):
+         mask16=None, ld_mask16=0, drop_p=0.0, drop_seed=0, group=None, b_planes=None, ld_bpl=0, colsum=None):
     """group = [(a_ptr, b_ptr, c_ptr), ...] (device addresses): that many independent products of this shape in ONE
     launch (ac_gemm_grouped; a / b / c then only carry strides)."""
     d = GemmDesc()
@@ -152,6 +152,7 @@ def gemm(mode, M, N, K, a: Mat, b: Mat, c: Mat, *, bias=None, act=ACT_NONE, pre_
     d.mask16, d.ld_mask16 = _p(mask16), ld_mask16
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.drop_step = _p(_STEP_DEV) if drop_p > 0.0 else None
+    d.colsum = _p(colsum)           # column sums of the stored values += (atomics): see ac_gemm_desc.colsum
     if b_planes is not None:      # split-bf16: B from cached (hi, lo) planes (a weight: split once per optimizer step)
         d.b_hi, d.b_lo, d.ld_bpl = _p(b_planes[0]), _p(b_planes[1]), int(ld_bpl)
     if group is not None:
@@ -702,80 +703,8 @@ def _exact_split(nkt: int, split: int) -> int:
     return -(-nkt // per)
 
 
-# --------------------------------------------------------------------------- grouped weight gradients
-# The weight gradients of nn.Linear layers that share a shape are independent small products: 9 ConvNeXt blocks of a
-# stage x (fc1, fc2), 4 encoder layers x (qkv, out, linear1, linear2) ... 68 launches per step at ~55 us each, a few
-# dozen workgroups with a split-K epilogue of atomics, 1.5 TB/s of their algorithmic bytes (round 3's dominant family).
-# They are collected while backward runs and launched as ONE grouped product per shape (ac_gemm_grouped: the chip fills
-# with 2-3 workgroups per CU, ramp-up and drain are paid once): when _WGRAD_GROUP_SIZE are waiting, when the same stream
-# moves on to another row count (= another stage), and at the end of the backward pass (autograd engine callback).
-# Only products that accumulate into a gradient sink are deferred.
-_WGRAD_GROUPS = True      # tests / A-B: False = every weight gradient launched where it is formed
-_WGRAD_GROUP_SIZE = 3     # launch as soon as this many products of a shape wait: three fill the chip, and nothing but a
-                          # remainder of <= 2 per shape is left for the end of the backward pass
-_wg_queue: dict = {}
-_wg_armed = False
-_wg_pending: set = set()  # ids of parameters whose gradient product is still waiting
-
-
-def grad_is_deferred(param) -> bool:
-    """True while `param`'s weight-gradient product sits in the grouped-launch queue: autograd's post-accumulate hook of
-    that parameter fires when its backward node returns (with no gradient), which is NOT yet the moment its slice of
-    the flat gradient buffer is complete (ddp.GradBuckets skips that report; _grad_written follows at the launch)."""
-    return id(param) in _wg_pending
-
-
-def _wg_flush_key(key):
-    """Launch the waiting products of one shape on the CURRENT stream (during backward that is the stream of the node
-    that triggered the flush = the stream that produced the operands; at the end of backward the caller's stream, after
-    it waited for the producers)."""
-    items = _wg_queue.pop(key, None)
-    if not items:
-        return
-    Nw, Kw, rows, split, _sid = key
-    g, x2, dw = items[0][:3]
-    if len(items) == 1:
-        gemm(AC_GEMM_TN, Nw, Kw, rows, mat(_p(g), Nw), mat(_p(x2), Kw), mat(_p(dw), Kw), accumulate=2, split_k=split)
-    else:
-        gemm(AC_GEMM_TN, Nw, Kw, rows, mat(_p(g), Nw), mat(_p(x2), Kw), mat(_p(dw), Kw), accumulate=2, split_k=split,
-             group=[(_p(i[0]), _p(i[1]), _p(i[2])) for i in items])
-    for i in items:
-        _wg_pending.discard(id(i[3]))
-        _grad_written(i[3])
-
-
-def flush_weight_gradients():
-    """Launch every weight-gradient product still waiting (end of backward; also callable directly)."""
-    global _wg_armed
-    _wg_armed = False
-    if not _wg_queue:
-        return
-    cur = torch.cuda.current_stream()
-    for st in {i[4].cuda_stream: i[4] for q in _wg_queue.values() for i in q}.values():
-        if st != cur:
-            cur.wait_stream(st)       # operands produced on a branch stream
-    for key in list(_wg_queue.keys()):
-        _wg_flush_key(key)
-
-
-def _defer_weight_grad(Nw, Kw, rows, g, x2, dw, wp):
-    global _wg_armed
-    st = torch.cuda.current_stream()
-    sid = st.cuda_stream
-    for key in [k for k in _wg_queue if k[4] == sid and k[2] != rows]:
-        _wg_flush_key(key)
-    key = (Nw, Kw, rows, _split_for(Nw, Kw, rows), sid)
-    q = _wg_queue.setdefault(key, [])
-    q.append((g, x2, dw, wp, st))
-    _wg_pending.add(id(wp))
-    if len(q) >= _WGRAD_GROUP_SIZE:
-        _wg_flush_key(key)
-    if not _wg_armed:
-        _wg_armed = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_weight_gradients)
-
-
 _PLANE_B = True   # tests / A-B: False = nn.Linear products split their weight operand on the fly
+_FUSE_DACT = True  # tests / A-B: False = activation backward + bias gradient as their own pass (ac_act_bwd_colsum)
 
 
 def _wplanes(wparam, N: int, K: int) -> dict:
@@ -850,7 +779,21 @@ class _Linear(Function):
         aux = pre if save_pre else (y if act != ACT_NONE else None)
         ctx.save_for_backward(x16 if ctx.b16 else x2, w, aux, colscale)  # bf16 mode keeps the bf16 copy
         ctx.wp, ctx.bp, ctx.csp = w, b, colscale
-        return y.reshape(*x.shape[:-1], N)
+        out = y.reshape(*x.shape[:-1], N)
+        # Activation backward in the CONSUMER's product (fp32 data flow): when this output (GELU / ReLU, optional
+        # dropout) feeds another Linear, that layer's input-gradient product applies act' (+ the dropout mask) in its
+        # epilogue and leaves this layer's bias gradient in its sink (ac_gemm_desc.dact / colsum) - the separate
+        # act' / mask / column-sum pass over the hidden tensor (ac_act_bwd_colsum: 3 reads + 1 write of it) is gone.
+        # `link` is shared by the two autograd nodes; the consumer fills it in during backward.
+        ctx.link = None
+        if (_FUSE_DACT and need_grad and not ctx.b16 and act in (ACT_GELU, ACT_RELU) and colscale is None and residual is None
+                and N % 4 == 0 and aux is not None):
+            ctx.link = {"act": act, "aux": aux, "bias": b, "drop_p": ctx.drop_p, "drop_seed": ctx.drop_seed, "N": N, "M": M,
+                        "done": False, "dx": None}
+            out._ac_link = ctx.link
+        src = getattr(x, "_ac_link", None)
+        ctx.src = src if (src is not None and not ctx.b16 and src["N"] == K and src["M"] == M) else None
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -877,7 +820,19 @@ class _Linear(Function):
                 _grad_written(ctx.csp)
         bias_done = colscale is not None and lsink is not None
         db_tmp = None
-        if colscale is None and (ctx.act != ACT_NONE or ctx.drop_p > 0.0):
+        link = getattr(ctx, "link", None)
+        fused_dact = link is not None and link["done"]
+        if fused_dact:
+            # the consumer's product already applied act' (+ mask) and summed this layer's bias gradient.  The gradient
+            # must be THE tensor that product wrote: anything else (autograd summed several consumers) would carry the
+            # activation backward only in part.
+            # (same storage AND same version: autograd sums several consumers' gradients in place when it can)
+            if link["dx"] != (dy.data_ptr(), dy._version, tuple(dy.shape)):
+                raise RuntimeError("fused activation backward: the hidden gradient is not the tensor the consumer's product "
+                                   "wrote (several consumers of an activated Linear output?) - set hipops._FUSE_DACT = False")
+            link["done"], link["dx"] = False, None
+            bias_done = True
+        if colscale is None and (ctx.act != ACT_NONE or ctx.drop_p > 0.0) and not fused_dact:
             g = torch.empty_like(dy2)
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             bsink = _sink(ctx.bp) if (not ctx.b16 and want_b and N % 2 == 0) else None
@@ -925,26 +880,35 @@ class _Linear(Function):
                      math=_lib.MATH_BF16_IN)
             else:
                 split = _small_grid_split(M, K, N)
+                src = getattr(ctx, "src", None)
+                bsrc = _sink(src["bias"]) if (src is not None and src["bias"] is not None) else None
                 if split > 1:
                     dx.zero_()
                     gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), accumulate=2,
                          split_k=split, **_wplanes(ctx.wp, N, K))
+                elif (src is not None and K % 4 == 0 and (src["bias"] is None or bsrc is not None)
+                      and src["aux"].is_contiguous()):
+                    # d(hidden) with the producer's activation backward, dropout mask and bias gradient in the epilogue
+                    gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), dact=_kact(src["act"]),
+                         aux=src["aux"], ld_aux=K, drop_p=src["drop_p"], drop_seed=src["drop_seed"], colsum=bsrc,
+                         **_wplanes(ctx.wp, N, K))
+                    if bsrc is not None:
+                        _grad_written(src["bias"])
+                    src["done"] = True
                 else:
                     gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), **_wplanes(ctx.wp, N, K))
             if not _is16only(dx):
                 dx = dx.reshape(ctx.shape_x)
             elif dx.shape != ctx.shape_x:
                 dx = _mark16only(dx.reshape(ctx.shape_x), dx._ac16)
+            if getattr(ctx, "src", None) is not None and ctx.src["done"]:
+                ctx.src["dx"] = (dx.data_ptr(), dx._version, tuple(dx.shape))   # what the producer's backward must receive
         if ctx.needs_input_grad[1]:
             wsink = _sink(ctx.wp)
             dw = wsink if wsink is not None else torch.zeros(N, K, device=dy.device, dtype=torch.float32)
             if ctx.b16:  # x2 is the bf16 copy saved by forward
                 gemm(AC_GEMM_TN, N, K, M, mat(_p(g16), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M), math=_lib.MATH_BF16_IN)
-            elif (wsink is not None and _WGRAD_GROUPS and _big(N, K, M) and N % 4 == 0 and K % 4 == 0
-                  and g.is_contiguous() and x2.is_contiguous()):
-                _defer_weight_grad(N, K, M, g, x2, wsink, ctx.wp)      # one grouped launch per shape, later
-                wsink = dw = None
             else:
                 gemm(AC_GEMM_TN, N, K, M, mat(_p(g), N), mat(_p(x2), K), mat(_p(dw), K),
                      accumulate=2, split_k=_split_for(N, K, M))
@@ -1792,21 +1756,21 @@ def global_max(x):
 
 
 # --------------------------------------------------------------------------- frequency-domain conv products
-import os as _os
-_FFTCONV = not _os.environ.get("APPLECIDER_NO_FFTCONV")   # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
+# (module-level switches below are set by tests / A-B tools through the attribute; the product reads no environment variable)
+_FFTCONV = True       # long-tap Conv1d products of the SpectraNet bank in the frequency domain (f32 / bf16x3 modes)
 _FFT_MATH = None      # arithmetic of the per-frequency products: None = the math mode's (fp32 or split-bf16 matrix cores)
 _FFT_FORCE = False    # tests: the transform form wherever the kernels cover the shape, whatever the cost rule says
 _FFT_MARGIN = 1.0     # the direct form must cost this many times the transform form's estimate before it is replaced
 _fft_tables: dict = {}
 
 
-_FFT_OVERLAP_SAVE = not _os.environ.get("APPLECIDER_FFT_NO_OVERLAP_SAVE")   # A/B: one sequence per sample only
-_FFT_RADIX3 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX3")               # A/B: power-of-two transform lengths only
-_FFT_SHARE = not _os.environ.get("APPLECIDER_FFT_NO_SHARE")                 # A/B: no sharing of spectra inside a bank
+_FFT_OVERLAP_SAVE = True   # A/B: False = one sequence per sample only
+_FFT_RADIX3 = True         # A/B: False = power-of-two transform lengths only
+_FFT_SHARE = True          # A/B: False = no sharing of spectra inside a bank
 # Transform lengths 9 * 2^m (1152 points for stage 2's k = 251, 288 for stage 3, 72 for stage 4's k = 11).  They were the
 # first plans on which the co-residency problem of the transform kernels showed (profiles/r03_fft_coresidency_
 # investigation.txt); with every transform workgroup alone on its CU they are as exact as the others.
-_FFT_RADIX9 = not _os.environ.get("APPLECIDER_FFT_NO_RADIX9")
+_FFT_RADIX9 = True
 
 
 def _fft_size(size):
@@ -1844,7 +1808,7 @@ def _fft_sizes():
 
 
 # relative cost per point of the >= 1024-point transform kernels in fft_plan (one workgroup per CU, 8 sequences)
-_FFT_LONG_WEIGHT = float(_os.environ.get("APPLECIDER_FFT_LONG_WEIGHT", "1.4"))
+_FFT_LONG_WEIGHT = 1.4
 
 
 def fft_plan(L: int, k: int):

@@ -227,6 +227,8 @@ class KernelTimer:
             # launch-latency bound (a few microseconds each).
             if Hh * Ww >= 100:
                 self.records.setdefault("dwconv7x7_fwd", []).append((s, e, 0.0, 2.0 * B * Hh * Ww * C * 4))
+            # ... and the whole family (every stage: SURVEY 8(d)'s 252 864 elements per sample), launch gaps included
+            self.records.setdefault("dwfamily_fwd", []).append((s, e, 0.0, 2.0 * B * Hh * Ww * C * 4))
             return rc
         lib.ac_dwconv7x7_fwd = timed
         orig_b = lib.ac_dwconv7x7_bwd
@@ -243,6 +245,21 @@ class KernelTimer:
                 self.records.setdefault("dwconv7x7_bwd", []).append((s, e, 0.0, 3.0 * B * Hh * Ww * C * 4))
             return rc
         lib.ac_dwconv7x7_bwd = timed_b
+        orig_r = lib.ac_dwconv7x7_bwd_res
+
+        def timed_r(dy, x, w, dres, dx, dw, db, B, Hh, Ww, C, variant, stream):
+            if not self.enabled:
+                return orig_r(dy, x, w, dres, dx, dw, db, B, Hh, Ww, C, variant, stream)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig_r(dy, x, w, dres, dx, dw, db, B, Hh, Ww, C, variant, stream)
+            e.record()
+            # + the shortcut's gradient read once when the block's two gradient paths meet in this kernel
+            if Hh * Ww >= 100:
+                self.records.setdefault("dwconv7x7_bwd", []).append((s, e, 0.0, (4.0 if dres else 3.0) * B * Hh * Ww * C * 4))
+            self.records.setdefault("dwfamily_bwd", []).append((s, e, 0.0, (4.0 if dres else 3.0) * B * Hh * Ww * C * 4))
+            return rc
+        lib.ac_dwconv7x7_bwd_res = timed_r
 
     def summary(self, peak_flops, peak_bytes):
         """Per kernel family: totals, and the same split by which roof bounds each LAUNCH
@@ -987,10 +1004,9 @@ def main():
         # the same kernel in the committed rocprofv3 kernel statistics of this command (kernel time only)
         try:
             import csv
-            stats = os.path.join(ROOT, "profiles", "r03_bench_%s_kernel_stats_single_stream.csv" % args.math)
-            if not os.path.exists(stats):
-                stats = os.path.join(ROOT, "profiles", "r02_bench_%s_kernel_stats_%s_single_stream.csv"
-                                     % (args.math, "v4" if args.math == "bf16x3" else "v3"))
+            import glob
+            stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_%s_kernel_stats_single_stream.csv"
+                                                  % args.math)))[-1]        # the latest round's statistics
             rows = list(csv.DictReader(open(stats)))
             for key, tags in (("roofline_hbm", ("dwconv_pipe_fwd_kernelILi15", "dwconv_rows_fwd_kernelILi15")),
                               ("roofline_hbm_bwd", ("dwconv_pipe_bwd_kernelILi15", "dwconv_rows_bwd_kernelILi15"))):
@@ -1016,6 +1032,12 @@ def main():
         out["roofline_hbm_bwd"].update(pending_rocprof.get("roofline_hbm_bwd", {}))
         if ceilings and "copy_GBps" in ceilings:
             out["roofline_hbm_bwd"]["frac_of_measured_ceiling"] = round(gbs / ceilings["hbm_ceiling_GBps"], 4)
+    for key, fam in (("roofline_hbm", "dwfamily_fwd"), ("roofline_hbm_bwd", "dwfamily_bwd")):
+        if key in out and fam in ks:
+            d = ks[fam]
+            out[key]["family_frac"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out[key]["family_note"] = ("all %d depthwise launches of the pass (every stage; SURVEY 8(d): 0.506 MB per sample "
+                                       "forward): algorithmic bytes / summed HIP-event brackets" % d["launches"])
     if "roofline_hbm" in out and ceilings and "copy_GBps" in ceilings:
         out["roofline_hbm"]["frac_of_measured_ceiling"] = round(out["roofline_hbm"]["achieved"] / ceilings["hbm_ceiling_GBps"], 4)
     if world == 1 and not args.no_cpu_baseline:

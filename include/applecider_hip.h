@@ -143,6 +143,12 @@ typedef struct ac_gemm_desc {
        from the planes (b.ptr is ignored): no split arithmetic per read, half the operand bytes. */
     const void *b_hi, *b_lo;
     int64_t ld_bpl;
+    /* nullable: the column sums of the fp32 values this product stores (after its whole epilogue) are ADDED to
+       colsum[0 .. N) with atomics.  With dact (+ drop_p: the forward epilogue's mask, same seed and index) the product
+       that forms a hidden layer's gradient applies that layer's activation backward itself and leaves the layer's bias
+       gradient here - no separate pass over the hidden tensor.  Needs the 16-byte epilogue (N % 4 == 0, aligned
+       pointers), one K piece, one product. */
+    float *colsum;
 } ac_gemm_desc;
 
 int ac_gemm(const ac_gemm_desc *d, ac_stream_t stream);

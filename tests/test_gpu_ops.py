@@ -1074,44 +1074,40 @@ def test_dwconv_with_the_block_shortcut(dev, B, H_, C, variant):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-def test_grouped_weight_gradients_equal_separate_launches(dev, mode):
-    """Round 4: weight gradients of same-shaped nn.Linear layers are collected during backward and launched as one
-    grouped product per shape (ac_gemm_grouped) - at a stage change, at 16 waiting, at the end of backward.  Same sums
-    as one launch per layer (split-K atomics: equal to rounding), the sinks are complete when backward() returns, and
-    nothing is left in the queue."""
+@pytest.mark.parametrize("mname,M,N,K,split", [("TN", 384, 1536, 4608, 8), ("TN", 96, 384, 20000, 40), ("NT", 1000, 96, 384, 1)])
+def test_gemm_grouped_equals_separate_launches(dev, mode, mname, M, N, K, split):
+    """ac_gemm_grouped: up to 16 same-shaped products in one launch, operands from a pointer table passed by value;
+    split-K pieces meet with atomics.  Measured in the step and NOT used by it (deferring the ConvNeXt / encoder weight
+    gradients into grouped launches cost 0.55 ms of overlap, profiles/r04_ab_switches.txt): the entry point stays for
+    hosts that have independent same-shaped products at hand."""
     from applecider_amd import hipops as H
     H.set_math(mode)
     try:
-        torch.manual_seed(3)
-        M1, M2 = 4608, 1152
-        shapes = [(384, 96), (96, 384)] * 5                  # alternating like fc1 / fc2 of a ConvNeXt stage
-        x0 = torch.randn(M1, 96, device=dev)
-        ws0 = [torch.randn(n, k, device=dev) / math.sqrt(k) for n, k in shapes]
-        tail0 = [torch.randn(64, 96, device=dev) / 10 for _ in range(18)]   # 18 layers of one shape at another row count
-        res = {}
-        for grouped in (True, False):
-            H._WGRAD_GROUPS = grouped
-            try:
-                ws = [torch.nn.Parameter(w.clone()) for w in ws0 + tail0]
-                for w in ws:
-                    w.grad = torch.zeros_like(w)
-                x = x0.clone().requires_grad_()
-                h = x
-                for i in range(0, 10, 2):
-                    h = H.linear(H.linear(h, ws[i], None, act="gelu"), ws[i + 1], None, residual=h)
-                h2 = h[:M2].contiguous()
-                out = 0
-                for w in ws[10:]:
-                    out = out + H.linear(h2, w, None).sum()
-                (h.square().sum() + out).backward()
-                assert not H._wg_queue and not H._wg_pending, "weight gradients still waiting after backward()"
-                torch.cuda.synchronize()
-            finally:
-                H._WGRAD_GROUPS = True
-            res[grouped] = [w.grad.clone() for w in ws] + [x.grad.clone()]
-        for i, (a, b) in enumerate(zip(res[True], res[False])):
-            assert float(b.abs().max()) > 0
-            close(a, b, tol=2e-6, name=f"grad {i}")
+        torch.manual_seed(M + N)
+        G = 5
+        md = {"TN": H.AC_GEMM_TN, "NT": H.AC_GEMM_NT}[mname]
+        if mname == "TN":
+            As = [torch.randn(K, M, device=dev) for _ in range(G)]
+            Bs = [torch.randn(K, N, device=dev) for _ in range(G)]
+            la, lb = M, N
+        else:
+            As = [torch.randn(M, K, device=dev) for _ in range(G)]
+            Bs = [torch.randn(N, K, device=dev) for _ in range(G)]
+            la, lb = K, K
+        acc = 2 if split > 1 else 0
+        c1 = [torch.zeros(M, N, device=dev) for _ in range(G)]
+        c2 = [torch.zeros(M, N, device=dev) for _ in range(G)]
+        for a, b, c in zip(As, Bs, c1):
+            H.gemm(md, M, N, K, H.mat(H._p(a), la), H.mat(H._p(b), lb), H.mat(H._p(c), N), accumulate=acc, split_k=split)
+        H.gemm(md, M, N, K, H.mat(H._p(As[0]), la), H.mat(H._p(Bs[0]), lb), H.mat(H._p(c2[0]), N), accumulate=acc,
+               split_k=split, group=[(H._p(a), H._p(b), H._p(c)) for a, b, c in zip(As, Bs, c2)])
+        torch.cuda.synchronize()
+        for i in range(G):
+            assert float(c1[i].abs().max()) > 0
+            if split > 1:
+                close(c2[i], c1[i], tol=2e-6, name=f"product {i}")
+            else:
+                assert torch.equal(c2[i], c1[i]), f"product {i}"
     finally:
         H.set_math("f32")
 
@@ -1157,3 +1153,66 @@ def test_linear_with_plane_fed_weight_equals_on_the_fly_split(dev, M, N, K):
                 assert torch.equal(res[tag][1], res[False][1]), f"dx differs ({tag})"
     finally:
         H.set_math("f32")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("act,p1,M,K,Hd,N", [("gelu", 0.0, 2304, 96, 384, 96), ("relu", 0.3, 1032, 128, 512, 128),
+                                             ("relu", 0.0, 700, 128, 512, 128), ("gelu", 0.0, 260, 40, 72, 24)])
+def test_activation_backward_in_the_consumers_product(dev, mode, act, p1, M, K, Hd, N):
+    """Round 4: y = fc2(drop(act(fc1(x)))) - fc2's input-gradient product applies act' (+ the dropout mask of fc1's
+    epilogue, same seed and index) in its epilogue and sums fc1's bias gradient into its sink (ac_gemm_desc.dact /
+    colsum), instead of a separate pass over the hidden tensor.  Every gradient equals the unfused path's (bias sums by
+    atomics: to rounding) and fp64 autograd."""
+    import itertools
+    from applecider_amd import hipops as H
+    H.set_math(mode)
+    try:
+        torch.manual_seed(11)
+        x0 = torch.randn(M, K, device=dev)
+        go = torch.randn(M, N, device=dev)
+        ps0 = [torch.randn(Hd, K, device=dev) / math.sqrt(K), torch.randn(Hd, device=dev) * 0.1,
+               torch.randn(N, Hd, device=dev) / math.sqrt(Hd), torch.randn(N, device=dev) * 0.1]
+        res = {}
+        for fused in (True, False):
+            H._FUSE_DACT = fused
+            H._seed_counter = itertools.count(4000)
+            try:
+                ps = [torch.nn.Parameter(t.clone()) for t in ps0]
+                for prm in ps:
+                    prm.grad = torch.zeros_like(prm)
+                x = x0.clone().requires_grad_()
+                y = H.mlp(x, ps[0], ps[1], ps[2], ps[3], act, p1=p1, p2=0.0, training=True, residual=None)
+                y.backward(go)
+                torch.cuda.synchronize()
+            finally:
+                H._FUSE_DACT = True
+            res[fused] = [y.detach().clone(), x.grad.clone()] + [prm.grad.clone() for prm in ps]
+        tol = 2e-6 if mode == "f32" else 4e-6
+        assert torch.equal(res[True][0], res[False][0])
+        for i, (a, b) in enumerate(zip(res[True][1:], res[False][1:])):
+            close(a, b, tol=tol, name=f"fused vs separate [{i}]")
+        if p1 == 0.0 and act == "gelu":      # (ReLU: a gate within rounding of zero flips between fp64 and the GPU product)
+            x64 = x0.double().cpu().requires_grad_()
+            w64 = [t.double().cpu().requires_grad_() for t in ps0]
+            h = x64 @ w64[0].t() + w64[1]
+            h = F.gelu(h) if act == "gelu" else F.relu(h)
+            y64 = h @ w64[2].t() + w64[3]
+            y64.backward(go.double().cpu())
+            ptol = 5e-6 if mode == "f32" else 5e-5
+            for i, (a, b) in enumerate(zip(res[True][1:], [x64.grad] + [t.grad for t in w64])):
+                close(a, b, tol=ptol, name=f"fused vs fp64 [{i}]")
+    finally:
+        H.set_math("f32")
+
+
+def test_fused_activation_backward_refuses_a_shared_hidden_tensor(dev):
+    """The fusion assumes the activated output has ONE consumer; a second consumer makes autograd sum two gradients, one
+    of which never saw act' - that must fail loudly, not silently."""
+    from applecider_amd import hipops as H
+    torch.manual_seed(1)
+    x = torch.randn(512, 64, device=dev, requires_grad=True)
+    w1, w2 = torch.randn(128, 64, device=dev, requires_grad=True), torch.randn(64, 128, device=dev, requires_grad=True)
+    h = H.linear(x, w1, None, act="gelu")
+    y = H.linear(h, w2, None)
+    with pytest.raises(RuntimeError, match="fused activation backward"):
+        (y.sum() + h.sum()).backward()
