@@ -58,11 +58,17 @@ template <bool SPLIT>
 __device__ __forceinline__ void img_store4(unsigned short *hi_img, unsigned short *lo_img, int row, int c,
                                            const f32x4 &v) {
     s16x4 h, l;
+    if constexpr (SPLIT) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        unsigned h0, l0, h1, l1;
+        ac_split_pair(v[0], v[1], h0, l0);   // 3 VALU instructions per element (ac_common.h)
+        ac_split_pair(v[2], v[3], h1, l1);
+        const u32x2 hh = {h0, h1}, ll = {l0, l1};
+        h = __builtin_bit_cast(s16x4, hh);
+        l = __builtin_bit_cast(s16x4, ll);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned short hb = a_f2bf(v[j]);
-        h[j] = (short)hb;
-        if (SPLIT) l[j] = (short)a_f2bf(v[j] - a_bf2f(hb));
+        for (int j = 0; j < 4; ++j) h[j] = (short)a_f2bf(v[j]);
     }
     const int off = img_off(row, c);
     *(s16x4 *)(hi_img + off) = h;
@@ -94,11 +100,17 @@ __device__ __forceinline__ bf16x8 col_frag(const unsigned short *img, int rbase,
 
 template <bool SPLIT>
 __device__ __forceinline__ void cvt8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+    if constexpr (SPLIT) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        unsigned h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const unsigned short hb = a_f2bf(v[j]);
-        hi[j] = (short)hb;
-        if (SPLIT) lo[j] = (short)a_f2bf(v[j] - a_bf2f(hb));
+        for (int j = 0; j < 4; ++j) ac_split_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
+        const u32x4 hh = {h[0], h[1], h[2], h[3]}, ll = {l[0], l[1], l[2], l[3]};
+        hi = __builtin_bit_cast(bf16x8, hh);
+        lo = __builtin_bit_cast(bf16x8, ll);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi[j] = (short)a_f2bf(v[j]);
     }
 }
 

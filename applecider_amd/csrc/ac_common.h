@@ -46,6 +46,27 @@ __device__ __forceinline__ float ac_h2f(unsigned short h) { return __builtin_bit
 #define AC_HALF_NAME "bf16"
 #endif
 
+// x -> (hi, lo) for a PAIR of floats, each packed as 2 x 16 bit (first element in the low half): hi = round16(x),
+// lo = round16(x - hi), both round-to-nearest-even - the split of the "bf16x3" arithmetic.  bf16 build: 3 VALU
+// instructions per element (one packed convert yields both hi halves, a shift and a mask turn them back into floats, one
+// packed convert for lo); the element-wise form (convert, shift, subtract, convert, and a v_perm to pack) took 4.5, and
+// the split sits in loops that are bound by VALU issue (wave64 without packed fp32: 4 cycles per instruction).
+// Bit-identical to the element-wise form: the same hardware convert.
+__device__ __forceinline__ void ac_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+#ifdef AC_HALF_F16
+    const unsigned short ha = ac_f2h(a), hb = ac_f2h(b);
+    hi = (unsigned)ha | ((unsigned)hb << 16);
+    lo = (unsigned)ac_f2h(a - ac_h2f(ha)) | ((unsigned)ac_f2h(b - ac_h2f(hb)) << 16);
+#else
+    typedef float ac_f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 ac_b2 __attribute__((ext_vector_type(2)));
+    const ac_f2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, ac_b2));
+    const ac_f2 l = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, ac_b2));
+#endif
+}
+
 static inline bool ac_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 __device__ __forceinline__ float ac_gelu(float x) {

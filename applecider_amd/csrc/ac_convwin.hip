@@ -137,17 +137,23 @@ __global__ __launch_bounds__(WM *WN * 64, 1) void conv1d_window_kernel(ConvWinPa
     wstore(S0, rb0);
     __syncthreads();  // window + first weight tile visible
     wload(1 < last ? 1 : last, rb0);
-    for (int kt = 0; kt < nkt; kt += 2) {
+    // two K tiles per trip, no exit between them (a `break` after the first half gives the loop header a back edge on
+    // which the first half's loads are in flight, and hipcc then waits for every load at the top of each trip)
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
         wload(kt + 2 < last ? kt + 2 : last, rb1);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt, S0);
         wstore(S1, rb0);
         __syncthreads();
-        if (kt + 1 >= nkt) break;
         wload(kt + 3 < last ? kt + 3 : last, rb0);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt + 1, S1);
         wstore(S0, rb1);
+        __syncthreads();
+    }
+    if (kt < nkt) {
+        compute(kt, S0);
         __syncthreads();
     }
 
@@ -703,17 +709,21 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
             wstore(S0, 0, rb0);
             __syncthreads();  // window + first weight tile visible
             wload(1 < last ? 1 : last, rb0);
-            for (int kt = 0; kt < ntile; kt += 2) {
+            int kt = 0;   // two K tiles per trip, no exit between them (see conv1d_window_kernel)
+            for (; kt + 1 < ntile; kt += 2) {
                 wload(kt + 2 < last ? kt + 2 : last, rb1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(tapoff(kt), S0);
                 wstore(S1, kt + 1, rb0);
                 __syncthreads();
-                if (kt + 1 >= ntile) break;
                 wload(kt + 3 < last ? kt + 3 : last, rb0);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(tapoff(kt + 1), S1);
                 wstore(S0, kt + 2, rb1);
+                __syncthreads();
+            }
+            if (kt < ntile) {
+                compute(tapoff(kt), S0);
                 __syncthreads();
             }
         }

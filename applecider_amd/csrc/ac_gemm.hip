@@ -391,6 +391,7 @@ struct Loader {
     const int32_t *goff;
     ac_rowmap rows;
     int64_t base[4];  // KC: row address + 4*c ; RC: inner offset (same for all i)
+    int64_t fbase[4]; // load_fast: everything of the address that does not depend on the K tile
     bool ok[4];
     int outer_n, inner_n;  // extents of the outer / inner index
     int t;
@@ -411,6 +412,7 @@ struct Loader {
                 ok[i] = r < outer_n;
                 r = r < outer_n ? r : outer_n - 1;
                 base[i] = ac_rowaddr(rows, r) + 4 * c;
+                fbase[i] = base[i];
             }
         } else {
             int col = tile_origin + 4 * (t & 31);
@@ -420,6 +422,7 @@ struct Loader {
             for (int i = 0; i < 4; ++i) {
                 base[i] = io;
                 ok[i] = cv;
+                fbase[i] = io + (int64_t)((t >> 5) + 8 * i) * rows.s3;
             }
         }
     }
@@ -457,11 +460,15 @@ struct Loader {
         if (KC) {
             const int k = kt * BK + 4 * (t & 7);
             const bool kv = k < inner_n;
-            const int ktc = kv ? kt : 0;
-            const int64_t ko = kv ? (goff ? (int64_t)ac_gload<int32_t>(goff + ktc) : (int64_t)ktc * BK) : 0;
+            // The table entry is read through a UNIFORM index and an always-valid pointer (scalar load, no branch): a
+            // conditional load put control flow into the pipelined loop, and hipcc then waits for EVERY load in flight
+            // at the loop header (s_waitcnt vmcnt(0)) - the prefetch distance of 2 was 1 in effect.
+            const int ktu = kt * BK < inner_n ? kt : 0;
+            const int32_t gv = ac_gload<int32_t>(goff ? goff + ktu : (const int32_t *)ptr);
+            const int64_t ku = goff ? (int64_t)gv : (int64_t)ktu * BK;
             mask = kv ? 0xFu : 0u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = ac_gload<f32x4>(ptr + base[i] + (kv ? ko : -4 * (t & 7)));
+            for (int i = 0; i < 4; ++i) v[i] = ac_gload<f32x4>(ptr + base[i] + (kv ? ku : -4 * (t & 7)));
         } else {
             mask = 0u;
 #pragma unroll
@@ -472,6 +479,18 @@ struct Loader {
                 mask |= (ok[i] && in) ? (1u << i) : 0u;
             }
         }
+    }
+
+    // Fast form, chosen per workgroup (uniform): the 128 rows / columns of this operand's tile are all inside, K is a
+    // multiple of 32 and (RC) the row map is the plain one.  No masks, no selects, no branches; a prefetch past the K range
+    // re-reads the last tile (its registers are never consumed).
+    // (KC: no K-offset table either - its scalar load and the wait for it sat in front of every tile's loads.  RC: the
+    // per-thread part of the row address is folded into fbase at init, the K tile adds one uniform offset.)
+    __device__ __forceinline__ void load_fast(int kt, int nkt, f32x4 (&v)[4]) const {
+        const int ktc = kt < nkt ? kt : nkt - 1;
+        const float *tp = ptr + (KC ? (int64_t)ktc * BK : (int64_t)ktc * BK * rows.s3);   // uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ac_gload<f32x4>(tp + fbase[i]);
     }
 
     __device__ __forceinline__ void store(float *tile, const f32x4 (&v)[4]) const {
@@ -924,23 +943,23 @@ constexpr int X3_RC_ELEMS = 32 * X3_RC_PITCH;
 
 // x -> (hi, lo) for 4 floats; packed 4 x bf16 each
 __device__ __forceinline__ void split4(const f32x4 &v, s16x4_t &hi, s16x4_t &lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned short h = f2bf(v[j]);
-        const float hf = ac_h2f(h);
-        hi[j] = (short)h;
-        lo[j] = (short)f2bf(v[j] - hf);
-    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, l0, h1, l1;
+    ac_split_pair(v[0], v[1], h0, l0);
+    ac_split_pair(v[2], v[3], h1, l1);
+    const u32x2 h = {h0, h1}, l = {l0, l1};
+    hi = __builtin_bit_cast(s16x4_t, h);
+    lo = __builtin_bit_cast(s16x4_t, l);
 }
 
-template <bool KC>
+template <bool KC, bool FAST = false>
 __device__ __forceinline__ void store_x3(const Loader<KC> &L, unsigned short *img_hi, unsigned short *img_lo,
                                          const f32x4 (&v)[4], unsigned mask) {
     const int t = L.t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s16x4_t hi, lo;
-        const bool in = (mask >> i) & 1u;
+        const bool in = FAST || ((mask >> i) & 1u);
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         split4(in ? v[i] : zero, hi, lo);
         int off;
@@ -1006,6 +1025,18 @@ struct PlaneLoader {
             mask |= in ? (1u << i) : 0u;
         }
     }
+    // fast form (see Loader::load_fast): the tile's 128 N entries inside, K a multiple of 32
+    __device__ __forceinline__ void load_fast(int kt, int nkt, bf16x8 (&vh)[2], bf16x8 (&vl)[2]) const {
+        const int ktc = kt < nkt ? kt : nkt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = KC ? (int64_t)(origin + (t >> 2) + 64 * i) * ld + ktc * BK + 8 * (t & 3)
+                                   : (int64_t)(ktc * BK + (t >> 4) + 16 * i) * ld + origin + 8 * (t & 15);
+            vh[i] = ac_gload<bf16x8>((const short *)hi + off);
+            vl[i] = ac_gload<bf16x8>((const short *)lo + off);
+        }
+    }
+    template <bool FAST = false>
     __device__ __forceinline__ void store(unsigned short *img_hi, unsigned short *img_lo, const bf16x8 (&vh)[2],
                                           const bf16x8 (&vl)[2], unsigned mask) const {
         const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1018,7 +1049,7 @@ struct PlaneLoader {
             } else {
                 off = ((t >> 4) + 16 * i) * X3_RC_PITCH + 8 * (t & 15);
             }
-            const bool in = (mask >> i) & 1u;
+            const bool in = FAST || ((mask >> i) & 1u);
             *(bf16x8 *)(img_hi + off) = in ? vh[i] : zero;
             *(bf16x8 *)(img_lo + off) = in ? vl[i] : zero;
         }
@@ -1113,43 +1144,90 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
         f32x4 f[B_PL ? 1 : 4];
         bf16x8 h[B_PL ? 2 : 1], l[B_PL ? 2 : 1];
     };
-    auto load_b = [&](int kt, BRegs &r, unsigned &m) {
-        if constexpr (B_PL)
-            lp.load_raw(kt, r.h, r.l, m);
-        else
-            lb.load_raw(kt, r.f, m);
-    };
-    auto stage_store = [&](unsigned short *stage, const f32x4 (&ra)[4], const BRegs &rb, unsigned ma, unsigned mb) {
-        store_x3<A_KC>(la, stage, stage + A_IMG, ra, ma);
-        if constexpr (B_PL)
-            lp.store(stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.h, rb.l, mb);
-        else
-            store_x3<B_KC>(lb, stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.f, mb);
-    };
-    unsigned short *S0 = sm16, *S1 = sm16 + STAGE;
-    f32x4 ra0[4], ra1[4];
-    BRegs rb0, rb1;
-    unsigned ma0, mb0, ma1, mb1;
-    la.load_raw(kt_begin, ra0, ma0);
-    load_b(kt_begin, rb0, mb0);
-    stage_store(S0, ra0, rb0, ma0, mb0);
-    __syncthreads();
-    la.load_raw(kt_begin + 1, ra0, ma0);
-    load_b(kt_begin + 1, rb0, mb0);
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-        la.load_raw(kt + 2, ra1, ma1);
-        load_b(kt + 2, rb1, mb1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(S0);
-        stage_store(S1, ra0, rb0, ma0, mb0);
+    // The loop exists in four copies, chosen per workgroup and operand (uniform): FA / FB = the operand's tile takes the
+    // fast loader (all 128 rows / columns inside, K a multiple of 32, no K-offset table for a KC operand, plain row map
+    // for an RC operand): no masks, no selects behind the split, no scalar loads or control flow between the loads -
+    // interior tiles, i.e. nearly all of them.  Edge
+    // tiles and gathered K rows keep the general loaders.
+    const int nkt = p.nkt;
+    auto mainloop = [&](auto fa_c, auto fb_c) {
+        constexpr bool FA = decltype(fa_c)::value, FB = decltype(fb_c)::value;
+        auto load_a = [&](int kt, f32x4 (&r)[4], unsigned &m) {
+            if constexpr (FA) {
+                la.load_fast(kt, nkt, r);
+                m = 0xFu;
+            } else {
+                la.load_raw(kt, r, m);
+            }
+        };
+        auto load_b = [&](int kt, BRegs &r, unsigned &m) {
+            if constexpr (B_PL) {
+                if constexpr (FB) {
+                    lp.load_fast(kt, nkt, r.h, r.l);
+                    m = 0x3u;
+                } else {
+                    lp.load_raw(kt, r.h, r.l, m);
+                }
+            } else if constexpr (FB) {
+                lb.load_fast(kt, nkt, r.f);
+                m = 0xFu;
+            } else {
+                lb.load_raw(kt, r.f, m);
+            }
+        };
+        auto stage_store = [&](unsigned short *stage, const f32x4 (&ra)[4], const BRegs &rb, unsigned ma, unsigned mb) {
+            store_x3<A_KC, FA>(la, stage, stage + A_IMG, ra, ma);
+            if constexpr (B_PL)
+                lp.template store<FB>(stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.h, rb.l, mb);
+            else
+                store_x3<B_KC, FB>(lb, stage + 2 * A_IMG, stage + 2 * A_IMG + B_IMG, rb.f, mb);
+        };
+        unsigned short *S0 = sm16, *S1 = sm16 + STAGE;
+        f32x4 ra0[4], ra1[4];
+        BRegs rb0, rb1;
+        unsigned ma0, mb0, ma1, mb1;
+        load_a(kt_begin, ra0, ma0);
+        load_b(kt_begin, rb0, mb0);
+        stage_store(S0, ra0, rb0, ma0, mb0);
         __syncthreads();
-        if (kt + 1 >= kt_end) break;
-        la.load_raw(kt + 3, ra0, ma0);
-        load_b(kt + 3, rb0, mb0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(S1);
-        stage_store(S0, ra1, rb1, ma1, mb1);
-        __syncthreads();
+        load_a(kt_begin + 1, ra0, ma0);
+        load_b(kt_begin + 1, rb0, mb0);
+        // Two K tiles per trip and NO exit between them: a `break` after the first half gave the loop header a second
+        // back edge on which the first half's loads are still in flight, and hipcc then waits for every load
+        // (s_waitcnt vmcnt(0)) at the top of each trip - the prefetch distance of 2 was 1 in effect.  The last trip of
+        // an even count stores one tile nobody reads; an odd count ends with the tile left in S0.
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {
+            load_a(kt + 2, ra1, ma1);
+            load_b(kt + 2, rb1, mb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S0);
+            stage_store(S1, ra0, rb0, ma0, mb0);
+            __syncthreads();
+            load_a(kt + 3, ra0, ma0);
+            load_b(kt + 3, rb0, mb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S1);
+            stage_store(S0, ra1, rb1, ma1, mb1);
+            __syncthreads();
+        }
+        if (kt < kt_end) {
+            compute(S0);
+            __syncthreads();   // the epilogues park their tiles in this buffer
+        }
+    };
+    {
+        const bool kfull = (d.K % BK) == 0;
+        const bool fa = kfull && tm * BM + BM <= d.M && (A_KC ? d.a.goff == nullptr : d.a.rows.r1 == 0);
+        const bool fb = kfull && tn * BN + BN <= d.N && (B_PL || (B_KC ? d.b.goff == nullptr : d.b.rows.r1 == 0));
+        if (fa && fb)
+            mainloop(std::true_type{}, std::true_type{});
+        else if (fa)
+            mainloop(std::true_type{}, std::false_type{});
+        else if (fb)
+            mainloop(std::false_type{}, std::true_type{});
+        else
+            mainloop(std::false_type{}, std::false_type{});
     }
 
     if (p.vec_epi == 3)

@@ -31,12 +31,13 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int R = 32;                                   // rows per block = one 32-row MFMA tile
 
 __device__ __forceinline__ void split4(const f32x4 &v, s16x4 &hi, s16x4 &lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned short h = ac_f2h(v[j]);
-        hi[j] = (short)h;
-        lo[j] = (short)ac_f2h(v[j] - ac_h2f(h));
-    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, l0, h1, l1;
+    ac_split_pair(v[0], v[1], h0, l0);   // 3 VALU instructions per element (ac_common.h)
+    ac_split_pair(v[2], v[3], h1, l1);
+    const u32x2 h = {h0, h1}, l = {l0, l1};
+    hi = __builtin_bit_cast(s16x4, h);
+    lo = __builtin_bit_cast(s16x4, l);
 }
 
 template <int G>

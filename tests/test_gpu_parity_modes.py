@@ -231,6 +231,53 @@ def test_gemm_bf16x3_accuracy(dev, mode, M, N, K):
     assert errs["f32"] <= 2e-5, errs
 
 
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("K", [96, 32 * 7, 32])
+def test_gemm_bf16x3_fast_and_general_loops_agree_bit_for_bit(dev, mode, K):
+    """gemm_x3_kernel walks K in one of four loop copies per workgroup: an operand whose 128-row tile is inside the
+    matrix (and K % 32 == 0) takes the loader without masks and without control flow, an edge tile the general one.
+    Same arithmetic, same order: the rows / columns of an EDGE tile must equal, bit for bit, the same rows / columns
+    computed as the interior of a zero-padded problem - for odd and even tile counts (the loop runs two tiles per trip
+    and finishes an odd count outside), and against fp64 to the mode's accuracy."""
+    from applecider_amd import hipops as H
+    H.set_math("bf16x3")
+    try:
+        gen = torch.Generator().manual_seed(K)
+        M, N, e = 128 + 16, 256 + 12, 16
+        a = torch.randn(M, K, generator=gen).to(dev)
+        b = torch.randn(N, K, generator=gen).to(dev)
+
+        def run(a_, b_):
+            m, n = a_.shape[0], b_.shape[0]
+            c = torch.full((m, n), float("nan"), device=dev)
+            if mode == "NT":
+                H.gemm(H.AC_GEMM_NT, m, n, K, H.mat(H._p(a_), K), H.mat(H._p(b_), K), H.mat(H._p(c), n))
+            elif mode == "NN":
+                bt = b_.t().contiguous()
+                H.gemm(H.AC_GEMM_NN, m, n, K, H.mat(H._p(a_), K), H.mat(H._p(bt), n), H.mat(H._p(c), n))
+            else:
+                at, bt = a_.t().contiguous(), b_.t().contiguous()
+                H.gemm(H.AC_GEMM_TN, m, n, K, H.mat(H._p(at), m), H.mat(H._p(bt), n), H.mat(H._p(c), n))
+            torch.cuda.synchronize()
+            return c
+        full = run(a, b)                                       # tiles (1, *) and (*, 2) are edge tiles
+        ref = (a.double() @ b.double().t()).float()
+        assert ((full - ref).abs().max() / ref.abs().max()).item() < 2e-5
+        # the edge rows / columns again, as the first rows / columns of problems made of whole tiles
+        a_pad = torch.zeros(128, K, device=dev)
+        a_pad[:e] = a[128:]
+        b_pad = torch.zeros(128, K, device=dev)
+        b_pad[:12] = b[256:]
+        rows = run(a_pad, b[:256])                             # A interior, B interior
+        assert torch.equal(rows[:e], full[128:, :256]), "edge rows differ from the interior form"
+        cols = run(a[:128], b_pad)
+        assert torch.equal(cols[:, :12], full[:128, 256:]), "edge columns differ from the interior form"
+        both = run(a_pad, b_pad)
+        assert torch.equal(both[:e, :12], full[128:, 256:])
+    finally:
+        H.set_math("f32")
+
+
 def test_gemm_bf16x3_exact_integers_and_epilogue(dev):
     """Exact-integer operands (every value a bf16 number): the split product must be exact, with an
     asymmetric B so that a transposed fragment map cannot pass; plus bias/GELU epilogue and split-K."""
