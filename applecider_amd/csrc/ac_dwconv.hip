@@ -607,7 +607,7 @@ int launch_pipe_fwd(const float *x, const float *w, const float *bias, float *y,
 //            — SEVEN running sums per thread instead of the 49 a (channel, row) thread would carry over all items
 //            (that form needed 256 registers and spilled)
 // The sums stay in registers over all items of the workgroup (fixed channel slice) and meet in LDS once at the end.
-template <int W, int SLOTS>
+template <int W, int SLOTS, bool RES>
 __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ dx,
     float *__restrict__ dw, float *__restrict__ dbias, int B, int C, int ncg, const float *__restrict__ dres) {
@@ -645,24 +645,31 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
     int cur = 0;
     for (int b = b0; b < B; b += bstep) {
         const bool more = b + bstep < B;
+        // the shortcut's gradient of this row (ConvNeXt block: d x = depthwise backward + d shortcut): loaded now,
+        // behind the next planes' DMA and ahead of the row's arithmetic, added when the row is stored.  The counted
+        // wait below still leaves exactly this item's W stores in flight.
+        // RES is a template parameter on purpose: with a run-time `dres ? load : 0` the two arms met in register copies
+        // right here, the copies waited for these loads - and for everything older on the in-order counter, i.e. the
+        // next planes' DMA issued just above: the double buffering did not overlap anything (60 vs 45 us per launch).
+        // The loads are issued from inline assembly ON PURPOSE as well: with compiler-visible loads in flight hipcc puts
+        // `s_waitcnt vmcnt(0)` in front of the first use of every LDS read of phase A (an LDS read may alias a pending
+        // LDS-DMA, and with ordinary loads pending too it no longer counts) - the same stall.  Nothing touches rres
+        // between here and the explicit wait in front of the stores.
+        float rres[W];
+        if constexpr (RES) {
+            const float *rp = dres + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
+#pragma unroll
+            for (int o = 0; o < W; ++o) {
+                const float *q = rp + (int64_t)o * C;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(rres[o]) : "v"(q) : "memory");
+            }
+        }
         if (more) {
             float *nb = plane + (cur ^ 1) * 2 * PL;
             dma_plane<W>(nb, dy + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
             dma_plane<W>(nb + PL, x + (int64_t)(b + bstep) * HW * C + cg * CG, C, wv, NWV);
         }
         const float *pdy = plane + cur * 2 * PL + c, *px = pdy + PL;
-        // the shortcut's gradient of this row (ConvNeXt block: d x = depthwise backward + d shortcut): loaded now,
-        // behind the next planes' DMA and ahead of the row's arithmetic, added when the row is stored.  The counted
-        // wait below still leaves exactly this item's W stores in flight.
-        float rres[W];
-        if (dres) {
-            const float *rp = dres + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
-#pragma unroll
-            for (int o = 0; o < W; ++o) rres[o] = ac_gload<float>(rp + (int64_t)o * C);
-        } else {
-#pragma unroll
-            for (int o = 0; o < W; ++o) rres[o] = 0.f;
-        }
         // ---- phase A: dx row
         {
             float out[W];
@@ -684,9 +691,19 @@ __global__ __launch_bounds__(32 * SLOTS, (32 * SLOTS) / 256) void dwconv_pipe_bw
                 __builtin_amdgcn_sched_barrier(0);
             }
             float *dxp = dx + (int64_t)b * HW * C + cglob + (int64_t)py * W * C;
+            if constexpr (RES) {
+                // rres (and, older on the in-order counter, nothing else of this item; younger: the next planes' DMA,
+                // which has had all of phase A to land)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]), "+v"(rres[W - 1])::"memory");
+#pragma unroll
+                for (int o = 1; o < W - 1; ++o) asm volatile("" : "+v"(rres[o]));
+            }
 #pragma unroll
             for (int o = 0; o < W; ++o) {   // W stores in every wave (a slot without a row repeats the last row)
-                *dxp = out[o] + rres[o];
+                if constexpr (RES)
+                    *dxp = out[o] + rres[o];
+                else
+                    *dxp = out[o];
                 dxp += C;
             }
         }
@@ -758,13 +775,20 @@ int launch_pipe_bwd(const float *dy, const float *x, const float *w, float *dx, 
     if (wgs > B * ncg) wgs = B * ncg;
     static bool configured = false;
     if (!configured && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_bwd_kernel<W, SLOTS>,
+        hipError_t e = hipFuncSetAttribute((const void *)dwconv_pipe_bwd_kernel<W, SLOTS, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)dwconv_pipe_bwd_kernel<W, SLOTS, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e - 2000;
         configured = true;
     }
-    hipLaunchKernelGGL((dwconv_pipe_bwd_kernel<W, SLOTS>), dim3(wgs), dim3(32 * SLOTS), lds, stream, dy, x, w, dx, dw,
-                       dbias, B, C, ncg, dres);
+    if (dres)
+        hipLaunchKernelGGL((dwconv_pipe_bwd_kernel<W, SLOTS, true>), dim3(wgs), dim3(32 * SLOTS), lds, stream, dy, x, w, dx,
+                           dw, dbias, B, C, ncg, dres);
+    else
+        hipLaunchKernelGGL((dwconv_pipe_bwd_kernel<W, SLOTS, false>), dim3(wgs), dim3(32 * SLOTS), lds, stream, dy, x, w, dx,
+                           dw, dbias, B, C, ncg, dres);
     AC_CHECK_LAUNCH();
     return AC_OK;
 }
