@@ -90,6 +90,58 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Zeroed temporaries of the backward pass (split-K / atomic accumulation targets, strided-gather gradients): slices of
+# ONE zero-filled buffer per stream and step instead of one fill launch each (32 ATen fills per step at B = 512).
+# A slice is a view: it keeps its buffer alive, nothing is ever handed out twice, and a buffer that runs out is replaced
+# by a fresh zero-filled one - there is no lifetime rule for callers to respect.  zero_pools_new_step() (called by
+# FlatParameters.zero_grad) sizes the next buffer to what the last step took.  Not used while a hipGraph is being
+# captured (a replay would find the slices dirty): plain torch.zeros there.
+_ZERO_POOL = True
+_ZERO_POOL_MIN, _ZERO_POOL_MAX = 4 << 20, 1 << 30
+
+
+class _ZeroPool:
+    __slots__ = ("buf", "off", "taken", "target")
+
+    def __init__(self):
+        self.buf, self.off, self.taken, self.target = None, 0, 0, _ZERO_POOL_MIN
+
+
+_zero_pools: dict = {}
+
+
+def _zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+    n = 1
+    for v in shape:
+        n *= v
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    if (not _ZERO_POOL or nbytes == 0 or nbytes > _ZERO_POOL_MAX or device.type != "cuda"
+            or torch.cuda.is_current_stream_capturing()):
+        return torch.zeros(shape, device=device, dtype=dtype)
+    key = (device.index, _stream())
+    pool = _zero_pools.get(key)
+    if pool is None:
+        pool = _zero_pools[key] = _ZeroPool()
+    nb = (nbytes + 255) & ~255
+    if pool.buf is None or pool.off + nb > pool.buf.numel():
+        size = max(nb, min(pool.target, _ZERO_POOL_MAX))
+        pool.buf, pool.off = torch.zeros(size, device=device, dtype=torch.uint8), 0
+    out = pool.buf[pool.off:pool.off + nbytes].view(dtype).view(shape)
+    pool.off += nb
+    pool.taken += nb
+    return out
+
+
+def zero_pools_new_step():
+    """Start a step with fresh, right-sized zero buffers (one fill per stream and step)."""
+    for pool in _zero_pools.values():
+        if pool.taken:
+            pool.target = max(_ZERO_POOL_MIN, int(pool.taken * 1.05) + 4096)
+        pool.buf, pool.off, pool.taken = None, 0, 0
+
+
 def _is16only(t) -> bool:
     return getattr(t, "_ac16_only", False)
 
@@ -840,7 +892,7 @@ class _Linear(Function):
                 # fp32 data flow: dropout mask, activation backward and the bias gradient in one pass
                 tgt = bsink
                 if tgt is None:
-                    tgt = db_tmp = torch.zeros(N, device=dy.device, dtype=torch.float32)
+                    tgt = db_tmp = _zeros((N,), dy.device)
                 _lib.check(_lib_().ac_act_bwd_colsum(_p(dy2), _p(aux) if ctx.act != ACT_NONE else None, _p(g), N,
                                                      _p(tgt), M, N, _kact(ctx.act), 1, ctx.drop_p, ctx.drop_seed,
                                                      _p(_STEP_DEV), _stream()), "ac_act_bwd_colsum")
@@ -865,7 +917,8 @@ class _Linear(Function):
             else:
                 g16 = cast16(g)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            split_dx = 1 if ctx.b16 else _small_grid_split(M, K, N)
+            dx = (_zeros((M, K), dy.device) if split_dx > 1 else torch.empty(M, K, device=dy.device, dtype=torch.float32))
             if ctx.b16 and ctx.x16only:
                 # the producer of x reads its output gradient in bf16 (LayerNorm backward of the conv
                 # bank): write only that; the fp32 tensor autograd carries is a placeholder
@@ -879,11 +932,10 @@ class _Linear(Function):
                 gemm(AC_GEMM_NT, M, K, N, mat(_p(g16), N), mat(_p(wT16), N), mat(_p(dx), K),
                      math=_lib.MATH_BF16_IN)
             else:
-                split = _small_grid_split(M, K, N)
+                split = split_dx
                 src = getattr(ctx, "src", None)
                 bsrc = _sink(src["bias"]) if (src is not None and src["bias"] is not None) else None
                 if split > 1:
-                    dx.zero_()
                     gemm(AC_GEMM_NN, M, K, N, mat(_p(g), N), mat(_p(w), K), mat(_p(dx), K), accumulate=2,
                          split_k=split, **_wplanes(ctx.wp, N, K))
                 elif (src is not None and K % 4 == 0 and (src["bias"] is None or bsrc is not None)
@@ -1419,7 +1471,7 @@ class _TowerBlocks(Function):
         dev = x.device
         dout = _chk(dout, "dout")
         arr = _tower_descs(plan, B, x, ldx, params, dout, save, ctx.sv_off)   # y slot unused by backward
-        dx = torch.zeros_like(x) if (plan.need_dx and ctx.needs_input_grad[0]) else None
+        dx = _zeros(x.shape, x.device) if (plan.need_dx and ctx.needs_input_grad[0]) else None
         grads, written = [], []
         for i, (blk, d) in enumerate(zip(plan.blocks, arr)):
             d.dy, d.lddy = _p(dout, _yoff(blk, B)), blk["ldy"]
@@ -1624,7 +1676,7 @@ class _PatchConv2x2(Function):
         dx = dw = db = None
         dy16 = cast16(dy2) if ctx.b16 else None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(x)  # border pixels dropped by the stride get zero gradient
+            dx = _zeros(x.shape, x.device)  # border pixels dropped by the stride get zero gradient
             if ctx.b16:
                 wT16 = cast16_wT(ctx.wp)
                 gemm(AC_GEMM_NT, M, 4 * Cn, Cout, mat(_p(dy16), Cout), mat(_p(wT16), Cout),
@@ -2247,7 +2299,7 @@ class _ConvGroup1d(Function):
             dgam = gsink if ln_direct else torch.zeros_like(ln_gamma)
             dbet = bsink if ln_direct else torch.zeros_like(ln_beta)
             fuse_bias = Ncat % 4 == 0 and Ncat <= 3072
-            bias_sums = torch.zeros(Ncat, device=dev, dtype=torch.float32) if fuse_bias else None
+            bias_sums = _zeros((Ncat,), dev) if fuse_bias else None
             # bf16 mode: the LayerNorm backward writes the bf16 operand of the gradient products
             # directly (into the zero-padded buffer when the input gradient is needed); the fp32
             # gradient of the conv outputs is never materialised
@@ -2363,7 +2415,7 @@ class _ConvGroup1d(Function):
                     off = Pmax - k // 2
                     shift8 = off % 8
                     Kp64 = (k + 7 + shift8 + 63) // 64 * 64
-                    dwexp8 = torch.zeros(8 * Cout, Kp64, device=dev, dtype=torch.float32)
+                    dwexp8 = _zeros((8 * Cout, Kp64), dev)
                     xoff = off - shift8
                     if conv_wgrad(dyp[0], dyp[1], L * Ncat, 8 * Ncat, 0, j * Cout, xpl[0], xpl[1], Lp, 8, 0,
                                   (Lp - xoff - 64) // 8 + 1, B, Lq, 8 * Cout, 64, Kp64 // 64, dwexp8, tap_row_step=8,
@@ -2378,7 +2430,7 @@ class _ConvGroup1d(Function):
                                            "a shape its dispatch admits")
                 if dyop is None:
                     dyop = dycat
-                dwexp = torch.zeros(8 * Cout, Kp, device=dev, dtype=torch.float32)
+                dwexp = _zeros((8 * Cout, Kp), dev)
                 gemm(AC_GEMM_TN, 8 * Cout, Kp, B * Lq, mat(_p(dyop), 8 * Ncat, goff=goff_c),
                      mat(_p(xpad, base), r1=Lq, r2=Lq, s1=Lp, s3=8), mat(_p(dwexp), Kp),
                      accumulate=2, split_k=_split_for(8 * Cout, Kp, B * Lq), math=mth)
@@ -2764,7 +2816,7 @@ class _TakeToken(Function):
     def backward(ctx, dout):
         B, T, D, idx = ctx.cfg
         dout = _chk(dout, "dout")
-        dz = torch.zeros(B, T, D, device=dout.device, dtype=torch.float32)
+        dz = _zeros((B, T, D), dout.device)
         _lib.check(_lib_().ac_copy2d(_p(dout), D, _p(dz, idx * D), T * D, B, D, _stream()),
                    "ac_copy2d")
         return dz, None

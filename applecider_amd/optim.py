@@ -122,6 +122,7 @@ class FlatParameters:
         # gradients stay views of the flat buffer (set_to_none would break the layout)
         if self.grad is not None:
             self.grad.zero_()
+            H.zero_pools_new_step()
             for p, off in zip(self.params, self.offsets):
                 if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                     p.grad = self.grad[off:off + p.numel()].view(p.shape)

@@ -1216,3 +1216,37 @@ def test_fused_activation_backward_refuses_a_shared_hidden_tensor(dev):
     y = H.linear(h, w2, None)
     with pytest.raises(RuntimeError, match="fused activation backward"):
         (y.sum() + h.sum()).backward()
+
+
+def test_zero_pool_hands_out_disjoint_zeroed_slices(dev):
+    """Backward's zeroed temporaries are slices of one zero-filled buffer per stream and step (hipops._zeros): every slice
+    is zero when handed out, no two overlap, a slice outlives its pool buffer, a new step starts a fresh buffer sized to
+    the last step's demand, and nothing is pooled while a graph is being captured."""
+    from applecider_amd import hipops as H
+    H.zero_pools_new_step()
+    a = H._zeros((1000, 3), dev)
+    b = H._zeros((7,), dev)
+    c = H._zeros((5 << 20,), dev)                       # larger than what is left: a fresh buffer
+    assert a.shape == (1000, 3) and a.dtype == torch.float32 and a.is_contiguous()
+    for t in (a, b, c):
+        assert t.data_ptr() % 256 == 0 and not t.any()
+    spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * 4) for t in (a, b, c))
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(2))
+    a.fill_(1.0)
+    b.fill_(2.0)
+    H.zero_pools_new_step()
+    d = H._zeros((1000, 3), dev)
+    assert not d.any() and float(a.sum()) == 3000.0 and float(b.sum()) == 14.0     # old slices untouched, still alive
+    pool = H._zero_pools[(dev.index if dev.index is not None else torch.cuda.current_device(), H._stream())]
+    assert pool.target >= (5 << 20)                      # sized to the last step's demand
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        e = H._zeros((64,), dev)
+        assert not e.any()
+    assert len(H._zero_pools) >= 2                       # one pool per stream
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        f = H._zeros((64,), dev)                         # plain torch.zeros inside a capture
+    g.replay()
+    torch.cuda.synchronize()
+    assert not f.any()
