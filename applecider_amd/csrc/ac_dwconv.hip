@@ -878,13 +878,17 @@ __global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__re
     const int b1 = min(B, (int)(blockIdx.y + 1) * spb);
     if (cv) {
         for (int b = blockIdx.y * spb + slot; b < b1; b += SM_SLOTS) {
-            float xi[P], d[P];
+            // the shortcut's gradient is loaded with the planes (at the store, each of the P stores waited for its own
+            // load: a load round trip per output pixel)
+            float xi[P], d[P], rr[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 xi[i] = x[((int64_t)b * P + i) * C + c];
                 d[i] = dy[((int64_t)b * P + i) * C + c];
-                dba += d[i];
+                rr[i] = dres ? dres[((int64_t)b * P + i) * C + c] : 0.f;
             }
+#pragma unroll
+            for (int i = 0; i < P; ++i) dba += d[i];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float a = 0.f;
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256) void dwconv_small_bwd_kernel(const float *__re
                     a = fmaf(d[o], wt[ty * T + tx], a);
                     dwa[ty * T + tx] = fmaf(d[o], xi[i], dwa[ty * T + tx]);
                 }
-                dx[((int64_t)b * P + i) * C + c] = dres ? a + dres[((int64_t)b * P + i) * C + c] : a;
+                dx[((int64_t)b * P + i) * C + c] = a + rr[i];
             }
         }
     }
