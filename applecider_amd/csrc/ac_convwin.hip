@@ -553,12 +553,30 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3_kernel(Co
             const int wr = Ls + tc - 1;   // window rows of one sample
             {
                 const unsigned short *a = aptr + (int64_t)t0 * d.a_row_stride + cch * CC;
-                for (int idx = t; idx < spt * wr * 8; idx += NT) {
-                    const int rr = idx >> 3, cc = idx & 7;
-                    const int sidx = spt > 1 ? rr / wr : 0, r = rr - sidx * wr;
-                    const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
-                    *(u32x4 *)(win_h + win_off<64>(rr, cc)) = ac_gload<u32x4>(src);
-                    *(u32x4 *)(win_l + win_off<64>(rr, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
+                // four index groups per trip, all eight loads issued before the first store: one group per trip was a
+                // load round trip per trip (ld ld / s_waitcnt vmcnt(0) in the generated code), and this workgroup is
+                // alone on its CU - nothing else covered it
+                const int nidx = spt * wr * 8;
+                for (int idx = t; idx < nidx; idx += 4 * NT) {
+                    u32x4 vh[4], vl[4];
+                    int off[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = idx + u * NT;
+                        const int idc = id < nidx ? id : idx;      // clamped: a valid address, the value is not stored
+                        const int rq = idc >> 3, cc = idc & 7;
+                        const int sidx = spt > 1 ? rq / wr : 0, r = rq - sidx * wr;
+                        const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
+                        vh[u] = ac_gload<u32x4>(src);
+                        vl[u] = ac_gload<u32x4>(src + d.a_lo_off);
+                        off[u] = id < nidx ? win_off<64>(rq, cc) : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) {
+                            *(u32x4 *)(win_h + off[u]) = vh[u];
+                            *(u32x4 *)(win_l + off[u]) = vl[u];
+                        }
                 }
             }
             // K tile kt of this group = tap GR * kt + grp of the chunk; a tile past the chunk's last tap loads
@@ -897,12 +915,30 @@ __global__ __launch_bounds__(GR *WM *WN * 64, 1) void conv1d_window_x3r_kernel(C
             const int wr = Ls + tstep * (tc - 1);
             {
                 const unsigned short *a = aptr + (int64_t)t0 * tstep * d.a_row_stride + cch * CC;
-                for (int idx = t; idx < spt * wr * 8; idx += NT) {
-                    const int rr_ = idx >> 3, cc = idx & 7;
-                    const int sidx = spt > 1 ? rr_ / wr : 0, r = rr_ - sidx * wr;
-                    const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
-                    *(u32x4 *)(win_h + win_off16(rr_, cc)) = ac_gload<u32x4>(src);
-                    *(u32x4 *)(win_l + win_off16(rr_, cc)) = ac_gload<u32x4>(src + d.a_lo_off);
+                // four index groups per trip, all eight loads issued before the first store: one group per trip was a
+                // load round trip per trip (ld ld / s_waitcnt vmcnt(0) in the generated code), and this workgroup is
+                // alone on its CU - nothing else covered it
+                const int nidx = spt * wr * 8;
+                for (int idx = t; idx < nidx; idx += 4 * NT) {
+                    u32x4 vh[4], vl[4];
+                    int off[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = idx + u * NT;
+                        const int idc = id < nidx ? id : idx;      // clamped: a valid address, the value is not stored
+                        const int rq = idc >> 3, cc = idc & 7;
+                        const int sidx = spt > 1 ? rq / wr : 0, r = rq - sidx * wr;
+                        const unsigned short *src = a + (int64_t)sidx * d.a_batch_stride + (int64_t)r * d.a_row_stride + cc * 8;
+                        vh[u] = ac_gload<u32x4>(src);
+                        vl[u] = ac_gload<u32x4>(src + d.a_lo_off);
+                        off[u] = id < nidx ? win_off16(rq, cc) : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) {
+                            *(u32x4 *)(win_h + off[u]) = vh[u];
+                            *(u32x4 *)(win_l + off[u]) = vl[u];
+                        }
                 }
             }
             const int ntile = (tc + GR - 1) / GR, nhalf = 2 * ntile;
