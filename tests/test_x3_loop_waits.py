@@ -59,3 +59,22 @@ def test_the_checker_recognises_a_draining_loop():
     (name, (start, insts)), = fns.items()
     (lo, hi, waits), = chk.trips(start, insts)
     assert chk.vm(waits) == [0] and hi - lo == 49
+
+
+def test_depthwise_backward_with_inline_asm_loads_never_spills():
+    """dwconv_pipe_bwd_kernel<.., RES = true> loads the shortcut's gradient from inline assembly and waits for it by
+    hand: the compiler does not know those registers are in flight, so it must never move them -
+    a spill to scratch between the load and the wait would save a stale value.  No scratch instruction may appear in
+    these kernels, and the hand-written wait must sit in front of the stores."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    ks = {n: t for n, t in chk.kernels(LIB, "dwconv_pipe_bwd_kernel").items() if "ELb1EEE" in n}
+    assert len(ks) == 2, sorted(ks)                      # 15 x 15 and 7 x 7
+    for name, insts in ks.items():
+        assert not [t for t in insts if t.startswith(("scratch_", "buffer_store", "buffer_load"))], name
+        text = [t.split("//")[0].strip() for t in insts]
+        first_store = next(i for i, t in enumerate(text) if t.startswith("global_store_dword"))
+        before = text[:first_store]
+        last_wait = max(i for i, t in enumerate(before) if t.startswith("s_waitcnt") and "vmcnt(0)" in t)
+        loads_after_wait = [t for t in before[last_wait:] if t.startswith("global_load_dword ")]
+        assert not loads_after_wait, (name, loads_after_wait)

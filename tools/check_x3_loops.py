@@ -22,11 +22,12 @@ ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):")
 TARGET = re.compile(r"<\S+\+0x([0-9a-fA-F]+)>\s*$")
 
 
-def functions(dis):
-    """-> {name: (start address, [(address, text)])} of the gemm_x3_kernel instantiations"""
+def functions(dis, head=None):
+    """-> {name: (start address, [(address, text)])} of the gemm_x3_kernel instantiations (or of the kernels `head` matches)"""
+    head = head or HEAD
     out, cur = {}, None
     for ln in dis.splitlines():
-        m = HEAD.match(ln)
+        m = head.match(ln)
         if m:
             cur = out.setdefault(m.group(2), (int(m.group(1), 16), []))
             continue
@@ -63,6 +64,22 @@ def trips(start, insts):
             continue   # not innermost
         res.append((lo, hi, [t.split("//")[0].strip() for t in body if "vmcnt" in t]))
     return res
+
+
+def kernels(lib, substr):
+    """-> {name: [instruction text]} of every kernel of the library whose mangled name contains `substr`"""
+    head = re.compile(r"^([0-9a-f]+) <(\S*" + re.escape(substr) + r"\S*)>:")
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, local)
+        subprocess.run([OBJDUMP, "--offloading", local], check=True, capture_output=True, cwd=tmp)
+        out = {}
+        for o in sorted(glob.glob(local + ".*gfx950*")):
+            dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", o], check=True, capture_output=True, text=True).stdout
+            if substr in dis:
+                for name, (_, insts) in functions(dis, head).items():
+                    out[name] = [t for _, t in insts]
+        return out
 
 
 def scan(lib):
