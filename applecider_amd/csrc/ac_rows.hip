@@ -950,7 +950,9 @@ extern "C" int ac_layernorm_bwd_split(const float *dy, int64_t lddy, const float
     int G = 0, J = 0;
     const bool dx16_ok = !dx16 || (((uintptr_t)dx16 & 7u) == 0 && lddx16 % 4 == 0);
     if (vec4 && dx16_ok && ln_sub_shape(C, &G, &J)) {
-        const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 2048);
+        // 512 workgroups, not 2048: every workgroup ends with 3 C atomics onto the same 3 C addresses, and at 2048 that
+        // flush - not the streaming - set the time (66 048 x 128: 81 -> 62 us; 131 072 x 768: 462 -> 440 us)
+        const int grid = grid_for_rows(rows, 4 * (64 / G) * 4, 512);
 #define LN_BWD_ARGS                                                                              \
     dim3(grid), dim3(ROWS_BLOCK), 0, stream, dy, lddy, x, ldx, mean, rstd, gamma, beta, dx, lddx,    \
         dgamma, dbeta, dxsum, rows, act, (unsigned short *)dx16, lddx16, seg_len, seg_pitch, seg_off,     \
