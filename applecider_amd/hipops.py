@@ -109,6 +109,8 @@ class _ZeroPool:
 
 
 _zero_pools: dict = {}
+_ITEMSIZE = {torch.float32: 4, torch.int32: 4, torch.bfloat16: 2, torch.float16: 2, torch.uint8: 1, torch.int64: 8,
+             torch.float64: 8, torch.int16: 2}
 
 
 def _zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
@@ -116,7 +118,7 @@ def _zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
     n = 1
     for v in shape:
         n *= v
-    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    nbytes = n * _ITEMSIZE.get(dtype, 4)
     if (not _ZERO_POOL or nbytes == 0 or nbytes > _ZERO_POOL_MAX or device.type != "cuda"
             or torch.cuda.is_current_stream_capturing()):
         return torch.zeros(shape, device=device, dtype=dtype)
