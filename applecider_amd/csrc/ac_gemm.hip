@@ -1186,17 +1186,28 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmParams p) {
         f32x4 ra0[4], ra1[4];
         BRegs rb0, rb1;
         unsigned ma0, mb0, ma1, mb1;
+        // Prologue: the first TWO tiles' loads go out back to back (most launches of the step are short-K - 3 to 16
+        // tiles - and a workgroup that asked for tile 1 only after tile 0 had landed and been stored paid two load
+        // latencies before its second tile); tile 0 is staged in S1 and the first step below is the second half of a
+        // trip, peeled: tile 0 computed from S1, tile 1 stored to S0, tile 2 requested.
         load_a(kt_begin, ra0, ma0);
         load_b(kt_begin, rb0, mb0);
-        stage_store(S0, ra0, rb0, ma0, mb0);
+        load_a(kt_begin + 1, ra1, ma1);
+        load_b(kt_begin + 1, rb1, mb1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_store(S1, ra0, rb0, ma0, mb0);
         __syncthreads();
-        load_a(kt_begin + 1, ra0, ma0);
-        load_b(kt_begin + 1, rb0, mb0);
+        load_a(kt_begin + 2, ra0, ma0);
+        load_b(kt_begin + 2, rb0, mb0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S1);
+        stage_store(S0, ra1, rb1, ma1, mb1);
+        __syncthreads();
         // Two K tiles per trip and NO exit between them: a `break` after the first half gave the loop header a second
         // back edge on which the first half's loads are still in flight, and hipcc then waits for every load
         // (s_waitcnt vmcnt(0)) at the top of each trip - the prefetch distance of 2 was 1 in effect.  The last trip of
         // an even count stores one tile nobody reads; an odd count ends with the tile left in S0.
-        int kt = kt_begin;
+        int kt = kt_begin + 1;
         for (; kt + 1 < kt_end; kt += 2) {
             load_a(kt + 2, ra1, ma1);
             load_b(kt + 2, rb1, mb1);
